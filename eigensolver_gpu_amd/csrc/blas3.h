@@ -1,0 +1,88 @@
+// blas3.h -- fp64 MFMA tile engine: one kernel family behind every BLAS-3 call site of the
+// reference: gemm (NN/CN/NC), her2k/syr2k, herk/syrk, trmm, trsm (via
+// inverted diagonal blocks + gemm), potrf, hegst.  Internal header.
+#pragma once
+#include <climits>
+
+#include "common.h"
+
+namespace eig {
+
+// Masks are expressed in the coordinates (sr, sc) of the STORED matrix element.
+enum Mask {
+    M_NONE = 0,
+    M_UPPER = 1,     // keep sr <= sc
+    M_SUPPER = 2,    // keep sr <  sc
+    M_LOWER = 3,     // keep sr >= sc
+    M_UNITTRAP = 4,  // d = sr - sc - moff : d == 0 -> 1, d > 0 -> 0   (larfb's V block)
+};
+
+// An operand is a logical (nidx x K) view X(idx,k):
+//   trans == 0 : X(idx,k) = p[idx + k*ld]   (idx contiguous in memory)
+//   trans == 1 : X(idx,k) = p[k + idx*ld]   (k contiguous in memory)
+// The A operand of C = A*B uses idx = row of C; the B operand is given through its
+// transpose view Bt(j,k) = B(k,j), idx = column of C.  k >= k1 switches to (p2, ld2) at
+// k - k1 (K-concatenation, used by her2k so C is touched once).
+template <class T> struct Operand {
+    const T* p = nullptr;
+    int ld = 0;
+    int trans = 0;
+    int conj = 0;
+    int mask = M_NONE;
+    int moff = 0;
+    const T* p2 = nullptr;
+    int ld2 = 0;
+    int k1 = INT_MAX;
+};
+
+template <class T> Operand<T> op_plain(const T* p, int ld, int trans, int conj) {
+    Operand<T> o;
+    o.p = p; o.ld = ld; o.trans = trans; o.conj = conj;
+    return o;
+}
+// BLAS-style helpers.  A operand (M x K) from op in {'N','T','C'} of a column-major matrix.
+template <class T> Operand<T> opA(char t, const T* p, int ld) {
+    return op_plain(p, ld, (t == 'N' || t == 'n') ? 0 : 1, (t == 'C' || t == 'c') ? 1 : 0);
+}
+// B operand (K x N) -> transpose view (N x K).
+template <class T> Operand<T> opB(char t, const T* p, int ld) {
+    return op_plain(p, ld, (t == 'N' || t == 'n') ? 1 : 0, (t == 'C' || t == 'c') ? 1 : 0);
+}
+
+struct Epi {
+    int uplo = 0;       // 0 full, 1 write only i<=j, 2 write only i>=j
+    int herm_diag = 0;  // force Im C(i,i) = 0
+};
+
+// C(MxN) = alpha * A * B + beta * C.
+template <class T>
+void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
+          T* C, int ldc, Epi epi = Epi());
+
+// Split-K variant for skinny outputs (larft's V^H V, larfb's C^H V): partial products are
+// written to scratch and summed in a fixed order (deterministic), then alpha/beta applied.
+template <class T>
+void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt,
+                 T beta, T* C, int ldc, int kchunk, Epi epi = Epi());
+
+// C(upper) -= V W^H + W V^H  (trans='N'), V,W n x k.
+template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc);
+
+// Blocked upper Cholesky of B (N x N, ld ldb); also leaves the inverses of the 64x64
+// diagonal blocks of U in scratch slot "invU" (used by every trsm).  Device info flag in
+// c.d_info[0] (0 = ok, else 1-based index of first bad pivot).
+template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb);
+// Rebuilds slot "invU" from an existing factor.
+template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
+
+// Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)).
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X <- U^-1 X
+template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X <- U^-H X
+template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X(mxn) <- X U^-1
+
+// A <- U^-H A U^-1 (upper triangle only is read/written).
+template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
+
+inline constexpr int kDiagBlk = 64;  // order of the inverted diagonal blocks
+
+}  // namespace eig

@@ -1,0 +1,598 @@
+// blas3.hip -- fp64 MFMA (v_mfma_f64_16x16x4_f64) tile engine for gfx950 and the blocked
+// routines built on it.  Replaces every cuBLAS/cuSOLVER BLAS-3 call site of the reference
+// (SURVEY.md 2.3): gemm, her2k/syr2k, herk/syrk, trmm, trsm, potrf, and the hegst blocking.
+//
+// Design (CDNA4-first, not a translation of any vendor kernel):
+//  * one kernel template  gemm_kernel<T, BM, BN, TA, TB>  with 4 wave64 waves in a 2x2 grid;
+//    operands are staged global -> registers -> LDS with the next K-slab's global loads in
+//    flight during the MFMA phase (register prefetch), complex data split into re/im planes
+//    in LDS so every MFMA operand is one conflict-free ds_read_b64;
+//  * LDS layouts are chosen per operand from how it sits in HBM ("idx-contiguous" or
+//    "k-contiguous") so global reads are always coalesced and LDS reads bank-conflict-free
+//    (row padding 16 doubles / 2 doubles, see MI355X_MICROARCH.md LDS table);
+//  * the MFMA is issued as D[n][m] (B fragment first) so that the 16 lanes of a fragment
+//    row own 16 consecutive rows of C -> 128/256-byte contiguous C read-modify-write;
+//  * triangular / unit-trapezoid masks, conjugation, K-concatenation (her2k in one pass over
+//    C) and triangular-output filtering are folded into the operand loader / epilogue, so no
+//    operand is ever physically modified (the reference stashes/zeros/restores blocks of A).
+#include "blas3.h"
+
+namespace eig {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <class T> struct GemmArgs {
+    int M, N, K;
+    T alpha, beta;
+    Operand<T> A, B;
+    T* C;
+    int ldc;
+    Epi epi;
+    int kchunk;      // >0: split-K, blockIdx.z owns [z*kchunk, (z+1)*kchunk)
+    T* P;            // split-K partial output (M x N per split, ld = M)
+    size_t pstride;
+};
+
+template <class T>
+__device__ __forceinline__ T fetch(const Operand<T>& o, int idx, int k, int nidx, int kend) {
+    T v = Tr<T>::zero();
+    if (idx < nidx && k < kend) {
+        const T* p = o.p;
+        int ld = o.ld, kk = k;
+        if (k >= o.k1) {
+            p = o.p2; ld = o.ld2; kk = k - o.k1;
+        }
+        int sr = o.trans ? kk : idx;
+        int sc = o.trans ? idx : kk;
+        bool keep = true, one = false;
+        if (o.mask == M_UPPER) keep = sr <= sc;
+        else if (o.mask == M_SUPPER) keep = sr < sc;
+        else if (o.mask == M_LOWER) keep = sr >= sc;
+        else if (o.mask == M_UNITTRAP) {
+            int d = sr - sc - o.moff;
+            keep = d < 0; one = (d == 0);
+        }
+        if (keep) {
+            v = p[(size_t)sr + (size_t)sc * ld];
+            if (o.conj) v = conj_(v);
+        } else if (one) {
+            v = Tr<T>::one();
+        }
+    }
+    return v;
+}
+
+// Restrict [kbeg,kend) to where a masked operand tile can be non-zero (skips the zero half of
+// triangular operands: trmm/trsm/hemm-by-two-gemms cost no wasted MFMAs beyond the diagonal tiles).
+template <class T>
+__device__ __forceinline__ void trim_k(const Operand<T>& o, int i0, int bsz, int& kbeg, int& kend) {
+    if (o.k1 != INT_MAX) return;
+    int ilast = i0 + bsz - 1;
+    if (o.mask == M_UPPER || o.mask == M_SUPPER) {
+        if (o.trans == 0) kbeg = max(kbeg, i0); else kend = min(kend, ilast + 1);
+    } else if (o.mask == M_LOWER) {
+        if (o.trans == 0) kend = min(kend, ilast + 1); else kbeg = max(kbeg, i0);
+    } else if (o.mask == M_UNITTRAP) {
+        if (o.trans == 0) kbeg = max(kbeg, i0 - o.moff); else kend = min(kend, ilast + o.moff + 1);
+    }
+}
+
+constexpr int BK = 16;
+
+template <class T, int BM, int BN, int TA, int TB>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
+    constexpr bool CX = Tr<T>::cx;
+    constexpr int NPL = CX ? 2 : 1;
+    constexpr int LDA = TA == 0 ? BM + 16 : BK + 2;
+    constexpr int LDB = TB == 0 ? BN + 16 : BK + 2;
+    constexpr int ASZ = TA == 0 ? BK * LDA : BM * LDA;
+    constexpr int BSZ = TB == 0 ? BK * LDB : BN * LDB;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    __shared__ double sm[NPL * (ASZ + BSZ)];
+    double* As = sm;
+    double* Bs = sm + NPL * ASZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
+    if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
+
+    int kbeg = 0, kend = g.K;
+    if (g.kchunk > 0) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    }
+    trim_k(g.A, i0, BM, kbeg, kend);
+    trim_k(g.B, j0, BN, kbeg, kend);
+    kbeg &= ~(BK - 1);
+
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    d4 acc[NPL][TM][TN];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    T ra[EA], rb[EB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            int idx, k;
+            if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
+            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+            ra[e] = fetch(g.A, i0 + idx, k0 + k, g.M, kend);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int idx, k;
+            if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
+            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+            rb[e] = fetch(g.B, j0 + idx, k0 + k, g.N, kend);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            int idx, k;
+            if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
+            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+            int off = TA == 0 ? k * LDA + idx : idx * LDA + k;
+            As[off] = real_(ra[e]);
+            if (CX) As[ASZ + off] = imag_(ra[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            int idx, k;
+            if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
+            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+            int off = TB == 0 ? k * LDB + idx : idx * LDB + k;
+            Bs[off] = real_(rb[e]);
+            if (CX) Bs[BSZ + off] = imag_(rb[e]);
+        }
+    };
+
+    const int fi = lane & 15, fk = lane >> 4;
+    if (kbeg < kend) gload(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (k0 + BK < kend) gload(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double ar[TM], ai[TM], br[TN], bi[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                int m = wm0 + a * 16 + fi, k = kk + fk;
+                int off = TA == 0 ? k * LDA + m : m * LDA + k;
+                ar[a] = As[off];
+                if (CX) ai[a] = As[ASZ + off];
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                int n = wn0 + b * 16 + fi, k = kk + fk;
+                int off = TB == 0 ? k * LDB + n : n * LDB + k;
+                br[b] = Bs[off];
+                if (CX) bi[b] = Bs[BSZ + off];
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    // D[n][m]: B fragment is the MFMA "A" operand -> lanes&15 of the result run along m.
+                    acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ar[a], acc[0][a][b], 0, 0, 0);
+                    if (CX) {
+                        acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], -ai[a], acc[0][a][b], 0, 0, 0);
+                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ar[a], acc[NPL - 1][a][b], 0, 0, 0);
+                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ai[a], acc[NPL - 1][a][b], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: lane owns (m = .. + (lane&15), n = .. + (lane>>4) + 4r)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int gi = i0 + wm0 + a * 16 + fi;
+                int gj = j0 + wn0 + b * 16 + fk + 4 * r;
+                if (gi >= g.M || gj >= g.N) continue;
+                if (g.epi.uplo == 1 && gi > gj) continue;
+                if (g.epi.uplo == 2 && gi < gj) continue;
+                T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
+                if (g.kchunk > 0) {
+                    g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
+                } else {
+                    T* cp = g.C + (size_t)gi + (size_t)gj * g.ldc;
+                    T out = g.alpha * v;
+                    if (!(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0)) out = out + g.beta * (*cp);
+                    if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
+                    *cp = out;
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int splits, const T* P, size_t pstride, T alpha,
+                                                            T beta, T* C, int ldc, Epi epi) {
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)M * N) return;
+    int i = (int)(id % M), j = (int)(id / M);
+    if (epi.uplo == 1 && i > j) return;
+    if (epi.uplo == 2 && i < j) return;
+    T s = Tr<T>::zero();
+    for (int z = 0; z < splits; ++z) s = s + P[(size_t)z * pstride + id];
+    T* cp = C + (size_t)i + (size_t)j * ldc;
+    T out = alpha * s;
+    if (!(real_(beta) == 0.0 && imag_(beta) == 0.0)) out = out + beta * (*cp);
+    if (epi.herm_diag && i == j) out = Tr<T>::realpart(out);
+    *cp = out;
+}
+
+template <class T, int BM, int BN>
+static void launch_gemm(hipStream_t st, const GemmArgs<T>& g, int splits) {
+    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
+    dim3 block(256);
+    int ta = g.A.trans, tb = g.B.trans;
+    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 0>), grid, block, 0, st, g);
+    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 1>), grid, block, 0, st, g);
+    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 0>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 1>), grid, block, 0, st, g);
+    EIG_HIP(hipGetLastError());
+}
+
+template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits) {
+    if (g.M <= 0 || g.N <= 0) return;
+    if constexpr (Tr<T>::cx) {
+        launch_gemm<T, 64, 64>(st, g, splits);
+    } else {
+        long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
+        if (tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
+        else launch_gemm<T, 64, 64>(st, g, splits);
+    }
+}
+
+template <class T>
+void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta, T* C,
+          int ldc, Epi epi) {
+    GemmArgs<T> g;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
+    g.kchunk = 0; g.P = nullptr; g.pstride = 0;
+    dispatch_gemm(c, st, g, 1);
+}
+
+template <class T>
+void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
+                 T* C, int ldc, int kchunk, Epi epi) {
+    if (M <= 0 || N <= 0) return;
+    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    int splits = (K + kchunk - 1) / kchunk;
+    if (splits <= 1) {
+        gemm(c, st, M, N, K, alpha, A, Bt, beta, C, ldc, epi);
+        return;
+    }
+    GemmArgs<T> g;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
+    g.kchunk = kchunk;
+    g.pstride = (size_t)M * N;
+    g.P = c.scratch<T>("splitk", g.pstride * splits);
+    dispatch_gemm(c, st, g, splits);
+    size_t total = (size_t)M * N;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, splits,
+                       (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi);
+    EIG_HIP(hipGetLastError());
+}
+
+template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc) {
+    if (n <= 0 || k <= 0) return;
+    Operand<T> A, B;
+    A.p = V; A.ld = ldv; A.trans = 0; A.conj = 0; A.k1 = k; A.p2 = W; A.ld2 = ldw;
+    B.p = W; B.ld = ldw; B.trans = 0; B.conj = 1; B.k1 = k; B.p2 = V; B.ld2 = ldv;
+    Epi e; e.uplo = 1; e.herm_diag = 1;
+    gemm<T>(c, st, n, n, 2 * k, Tr<T>::make(-1.0, 0.0), A, B, Tr<T>::one(), C, ldc, e);
+}
+
+// ------------------------------------------------------------------------------------------
+// 64x64 base kernels (one workgroup, matrix resident in LDS)
+// ------------------------------------------------------------------------------------------
+constexpr int DB = kDiagBlk;
+constexpr int DBL = DB + 1;  // LDS leading dimension
+
+// In-LDS upper Cholesky (optional) followed by in-place inversion of the upper factor.
+//   do_chol = 1: a <- chol(a) (upper), written back to Ublk; info <- first bad pivot (1-based, global)
+//   inv block written to invblk (DB x DB, ld DB, identity-padded, zero below the diagonal).
+template <class T>
+__global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, int ldu, T* invU, int do_chol, int k0_single,
+                                                         int* info) {
+    __shared__ T a[DB * DBL];
+    __shared__ T colv[DB];
+    __shared__ double piv;
+    const int tid = threadIdx.x;
+    const int blk = (k0_single >= 0) ? k0_single / DB : blockIdx.x;
+    const int k0 = blk * DB;
+    const int nb = min(DB, n_total - k0);
+    T* Ublk = Umat + (size_t)k0 + (size_t)k0 * ldu;
+    T* inv = invU + (size_t)blk * DB * DB;
+
+    for (int e = tid; e < DB * DB; e += 256) {
+        int r = e % DB, cc = e / DB;
+        T v = Tr<T>::zero();
+        if (r < nb && cc < nb && r <= cc) v = Ublk[(size_t)r + (size_t)cc * ldu];
+        else if (r == cc) v = Tr<T>::one();
+        a[r + cc * DBL] = v;
+    }
+    __syncthreads();
+
+    if (do_chol) {
+        for (int j = 0; j < nb; ++j) {
+            if (tid == 0) {
+                double d = real_(a[j + j * DBL]);
+                if (!(d > 0.0)) {
+                    atomicCAS(info, 0, k0 + j + 1);
+                    d = 1.0;
+                }
+                piv = sqrt(d);
+                a[j + j * DBL] = Tr<T>::make(piv, 0.0);
+            }
+            __syncthreads();
+            double inv_p = 1.0 / piv;
+            for (int cc = j + 1 + tid; cc < nb; cc += 256) a[j + cc * DBL] = a[j + cc * DBL] * inv_p;
+            __syncthreads();
+            int rem = nb - j - 1;
+            for (int e = tid; e < rem * rem; e += 256) {
+                int r = j + 1 + e % rem, cc = j + 1 + e / rem;
+                if (r <= cc) {
+                    T v = a[r + cc * DBL];
+                    T t = Tr<T>::zero();
+                    fmac_(t, a[j + r * DBL], a[j + cc * DBL]);
+                    a[r + cc * DBL] = v - t;
+                }
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < nb * nb; e += 256) {
+            int r = e % nb, cc = e / nb;
+            if (r <= cc) Ublk[(size_t)r + (size_t)cc * ldu] = a[r + cc * DBL];
+        }
+        __syncthreads();
+    }
+
+    // in-place inverse of the upper triangular a (LAPACK ?trti2 'U','N' order)
+    for (int j = 0; j < DB; ++j) {
+        if (tid < DB) colv[tid] = (tid < j) ? a[tid + j * DBL] : Tr<T>::zero();
+        __syncthreads();
+        T ajj;
+        {
+            T d = a[j + j * DBL];
+            double den = abs2_(d);
+            ajj = conj_(d) * (1.0 / den);  // 1/d
+        }
+        if (tid < j) {
+            T s = Tr<T>::zero();
+            for (int k = tid; k < j; ++k) fma_(s, a[tid + k * DBL], colv[k]);
+            a[tid + j * DBL] = -(s * ajj);
+        }
+        __syncthreads();
+        if (tid == 0) a[j + j * DBL] = ajj;
+        __syncthreads();
+    }
+    for (int e = tid; e < DB * DB; e += 256) {
+        int r = e % DB, cc = e / DB;
+        inv[r + cc * DB] = (r <= cc) ? a[r + cc * DBL] : Tr<T>::zero();
+    }
+}
+
+// A_kk <- invU^H * Herm(A_kk) * invU for one diagonal block (upper triangle in/out, real diagonal).
+template <class T>
+__global__ void __launch_bounds__(256) hegs2_block_kernel(int nb, T* Ablk, int lda, const T* inv) {
+    __shared__ T h[DB * DBL];
+    __shared__ T x[DB * DBL];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DB * DB; e += 256) {
+        int r = e % DB, cc = e / DB;
+        T v = Tr<T>::zero();
+        if (r < nb && cc < nb) {
+            if (r < cc) v = Ablk[(size_t)r + (size_t)cc * lda];
+            else if (r == cc) v = Tr<T>::realpart(Ablk[(size_t)r + (size_t)cc * lda]);
+            else v = conj_(Ablk[(size_t)cc + (size_t)r * lda]);
+        }
+        h[r + cc * DBL] = v;
+        x[r + cc * DBL] = inv[r + cc * DB];
+    }
+    __syncthreads();
+    // tmp = H * X   (X upper: sum over k <= col)
+    T t[DB * DB / 256];
+#pragma unroll
+    for (int q = 0; q < DB * DB / 256; ++q) {
+        int e = tid + q * 256;
+        int r = e % DB, cc = e / DB;
+        T s = Tr<T>::zero();
+        for (int k = 0; k <= cc; ++k) fma_(s, h[r + k * DBL], x[k + cc * DBL]);
+        t[q] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < DB * DB / 256; ++q) {
+        int e = tid + q * 256;
+        h[(e % DB) + (e / DB) * DBL] = t[q];
+    }
+    __syncthreads();
+    // out = X^H * tmp  (X^H lower: sum over k <= row); write upper part only
+#pragma unroll
+    for (int q = 0; q < DB * DB / 256; ++q) {
+        int e = tid + q * 256;
+        int r = e % DB, cc = e / DB;
+        if (r < nb && cc < nb && r <= cc) {
+            T s = Tr<T>::zero();
+            for (int k = 0; k <= r; ++k) fmac_(s, x[k + r * DBL], h[k + cc * DBL]);
+            if (r == cc) s = Tr<T>::realpart(s);
+            Ablk[(size_t)r + (size_t)cc * lda] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Blocked (recursive) routines
+// ------------------------------------------------------------------------------------------
+static inline int split_n1(int n) {
+    int nblk = (n + DB - 1) / DB;
+    return ((nblk + 1) / 2) * DB;
+}
+
+template <class T> static Operand<T> op_inv(const T* inv, int trans, int conj) {
+    Operand<T> o;
+    o.p = inv; o.ld = DB; o.trans = trans; o.conj = conj; o.mask = M_UPPER;
+    return o;
+}
+
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
+    if (n <= 0 || m <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (n <= DB) {
+        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
+                Tr<T>::zero(), X, ldx);
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx);
+    gemm<T>(c, st, n1, m, n2, Tr<T>::make(-1.0, 0.0), opA('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
+            opB('N', X + n1, ldx), Tr<T>::one(), X, ldx);
+    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx);
+}
+
+template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
+    if (n <= 0 || m <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (n <= DB) {
+        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
+                Tr<T>::zero(), X, ldx);
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    trsm_LUC(c, st, n1, m, U, ldu, k0, X, ldx);
+    gemm<T>(c, st, n2, m, n1, Tr<T>::make(-1.0, 0.0), opA('C', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
+            opB('N', X, ldx), Tr<T>::one(), X + n1, ldx);
+    trsm_LUC(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx);
+}
+
+// X is m x n (m rows), solve X <- X U^-1 with U = U(k0:k0+n, k0:k0+n)
+template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
+    if (n <= 0 || m <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (n <= DB) {
+        gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
+                Tr<T>::zero(), X, ldx);
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    trsm_RUN(c, st, n1, m, U, ldu, k0, X, ldx);
+    gemm<T>(c, st, m, n2, n1, Tr<T>::make(-1.0, 0.0), opA('N', X, ldx),
+            opB('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu), Tr<T>::one(), X + (size_t)n1 * ldx, ldx);
+    trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx);
+}
+
+template <class T> static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU) {
+    if (n <= 0) return;
+    if (n <= DB) {
+        hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(256), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info);
+        EIG_HIP(hipGetLastError());
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    potrf_rec(c, st, Ntot, n1, k0, B, ldb, invU);
+    T* B12 = B + (size_t)k0 + (size_t)(k0 + n1) * ldb;
+    T* B22 = B + (size_t)(k0 + n1) + (size_t)(k0 + n1) * ldb;
+    trsm_LUC(c, st, n1, n2, B, ldb, k0, B12, ldb);
+    Epi e; e.uplo = 1; e.herm_diag = 1;
+    gemm<T>(c, st, n2, n2, n1, Tr<T>::make(-1.0, 0.0), opA('C', (const T*)B12, ldb), opB('N', (const T*)B12, ldb),
+            Tr<T>::one(), B22, ldb, e);
+    potrf_rec(c, st, Ntot, n2, k0 + n1, B, ldb, invU);
+}
+
+template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
+    int nblk = (N + DB - 1) / DB;
+    T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), st));
+    potrf_rec(c, st, N, N, 0, B, ldb, invU);
+}
+
+template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
+    int nblk = (N + DB - 1) / DB;
+    if (nblk <= 0) return;
+    T* invU = c.scratch<T>("invU", (size_t)nblk * DB * DB);
+    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nblk), dim3(256), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1,
+                       c.d_info);
+    EIG_HIP(hipGetLastError());
+}
+
+template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu) {
+    if (n <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (n <= DB) {
+        hipLaunchKernelGGL((hegs2_block_kernel<T>), dim3(1), dim3(256), 0, st, n, A + (size_t)k0 + (size_t)k0 * lda, lda,
+                           invU + (size_t)(k0 / DB) * DB * DB);
+        EIG_HIP(hipGetLastError());
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    hegst_rec(c, st, n1, k0, A, lda, U, ldu);
+    T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
+    T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
+    T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
+    const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
+    const T mhalf = Tr<T>::make(-0.5, 0.0);
+    // A12 <- U11^-H A12                                   (zhegst_gpu.F90:87-88)
+    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda);
+    auto hemm_half = [&]() {
+        // A12 -= 1/2 Herm(A11) U12, Herm(A11) = triu(A11) + striu(A11)^H: two K-trimmed gemms
+        Operand<T> up = op_plain((const T*)A11, lda, 0, 0);
+        up.mask = M_UPPER;
+        Operand<T> lo = op_plain((const T*)A11, lda, 1, 1);
+        lo.mask = M_SUPPER;
+        gemm<T>(c, st, n1, n2, n1, mhalf, up, opB('N', U12, ldu), Tr<T>::one(), A12, lda);
+        gemm<T>(c, st, n1, n2, n1, mhalf, lo, opB('N', U12, ldu), Tr<T>::one(), A12, lda);
+    };
+    hemm_half();  // :93-94
+    {
+        // A22 -= A12^H U12 + U12^H A12 (upper)              (:95-96), one pass over A22
+        Operand<T> Ao, Bo;
+        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
+        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+    }
+    hemm_half();  // :100-101
+    // A12 <- A12 U22^-1                                   (:103-104)
+    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda);
+    hegst_rec(c, st, n2, k0 + n1, A, lda, U, ldu);
+}
+
+template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+    hegst_rec(c, st, N, 0, A, lda, U, ldu);
+}
+
+// explicit instantiations
+#define INST(T)                                                                                                          \
+    template void gemm<T>(Ctx&, hipStream_t, int, int, int, T, const Operand<T>&, const Operand<T>&, T, T*, int, Epi);   \
+    template void gemm_splitk<T>(Ctx&, hipStream_t, int, int, int, T, const Operand<T>&, const Operand<T>&, T, T*, int,  \
+                                 int, Epi);                                                                              \
+    template void her2k_un<T>(Ctx&, hipStream_t, int, int, const T*, int, const T*, int, T*, int);                       \
+    template void potrf_upper<T>(Ctx&, hipStream_t, int, T*, int);                                                       \
+    template void build_invU<T>(Ctx&, hipStream_t, int, const T*, int);                                                  \
+    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
+    template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
+    template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
+    template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);
+INST(double)
+INST(cplx)
+
+}  // namespace eig

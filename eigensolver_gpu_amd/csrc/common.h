@@ -1,0 +1,127 @@
+// common.h -- shared types for the gfx950 eigensolver library (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace eig {
+
+// ---- complex(8): interleaved (re,im), same layout as Fortran complex(8) -------------------
+struct alignas(16) cplx {
+    double x, y;
+};
+
+__host__ __device__ inline cplx mkc(double r, double i) { return cplx{r, i}; }
+__host__ __device__ inline cplx operator+(cplx a, cplx b) { return cplx{a.x + b.x, a.y + b.y}; }
+__host__ __device__ inline cplx operator-(cplx a, cplx b) { return cplx{a.x - b.x, a.y - b.y}; }
+__host__ __device__ inline cplx operator-(cplx a) { return cplx{-a.x, -a.y}; }
+__host__ __device__ inline cplx operator*(cplx a, cplx b) {
+    return cplx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__host__ __device__ inline cplx operator*(double s, cplx a) { return cplx{s * a.x, s * a.y}; }
+__host__ __device__ inline cplx operator*(cplx a, double s) { return cplx{s * a.x, s * a.y}; }
+__host__ __device__ inline cplx& operator+=(cplx& a, cplx b) { a.x += b.x; a.y += b.y; return a; }
+__host__ __device__ inline cplx& operator-=(cplx& a, cplx b) { a.x -= b.x; a.y -= b.y; return a; }
+
+// ---- scalar traits: one code path for real(8) and complex(8) -----------------------------
+__host__ __device__ inline double conj_(double a) { return a; }
+__host__ __device__ inline cplx conj_(cplx a) { return cplx{a.x, -a.y}; }
+__host__ __device__ inline double real_(double a) { return a; }
+__host__ __device__ inline double real_(cplx a) { return a.x; }
+__host__ __device__ inline double imag_(double) { return 0.0; }
+__host__ __device__ inline double imag_(cplx a) { return a.y; }
+__host__ __device__ inline double abs2_(double a) { return a * a; }
+__host__ __device__ inline double abs2_(cplx a) { return a.x * a.x + a.y * a.y; }
+// a += b*c
+__host__ __device__ inline void fma_(double& a, double b, double c) { a = fma(b, c, a); }
+__host__ __device__ inline void fma_(cplx& a, cplx b, cplx c) {
+    a.x = fma(b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
+    a.y = fma(b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
+}
+// a += conj(b)*c
+__host__ __device__ inline void fmac_(double& a, double b, double c) { a = fma(b, c, a); }
+__host__ __device__ inline void fmac_(cplx& a, cplx b, cplx c) {
+    a.x = fma(b.x, c.x, a.x); a.x = fma(b.y, c.y, a.x);
+    a.y = fma(b.x, c.y, a.y); a.y = fma(-b.y, c.x, a.y);
+}
+
+template <class T> struct Tr;
+template <> struct Tr<double> {
+    static constexpr bool cx = false;
+    __host__ __device__ static double make(double r, double) { return r; }
+    __host__ __device__ static double zero() { return 0.0; }
+    __host__ __device__ static double one() { return 1.0; }
+    __host__ __device__ static double realpart(double a) { return a; }  // value with imag dropped
+};
+template <> struct Tr<cplx> {
+    static constexpr bool cx = true;
+    __host__ __device__ static cplx make(double r, double i) { return cplx{r, i}; }
+    __host__ __device__ static cplx zero() { return cplx{0.0, 0.0}; }
+    __host__ __device__ static cplx one() { return cplx{1.0, 0.0}; }
+    __host__ __device__ static cplx realpart(cplx a) { return cplx{a.x, 0.0}; }
+};
+
+// ---- error handling ----------------------------------------------------------------------
+#define EIG_HIP(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            fprintf(stderr, "eigsolve: HIP error %s at %s:%d: %s\n", hipGetErrorName(e__), __FILE__,  \
+                    __LINE__, #call);                                                                 \
+            throw eig::HipFail{e__};                                                                  \
+        }                                                                                             \
+    } while (0)
+
+struct HipFail {
+    hipError_t err;
+};
+
+// ---- per-(thread, device) context (replaces module eigsolve_vars) ------------------------
+using stedc_fn = void (*)(const char*, const int*, double*, double*, double*, const int*, double*, const int*,
+                          int*, const int*, int*, size_t);
+
+enum Phase { PH_POTRF = 0, PH_GST, PH_TRD, PH_STEDC, PH_BT, PH_TRSM, PH_D2H, PH_TOTAL, PH_COUNT };
+
+struct Ctx {
+    int dev = -1;
+    hipStream_t s1 = nullptr;  // compute stream
+    hipStream_t s2 = nullptr;  // copy / overlap stream
+    hipEvent_t ev[2 * PH_COUNT] = {};
+    hipEvent_t evA = nullptr, evB = nullptr;
+    std::map<std::string, std::pair<void*, size_t>> slots;  // named grow-only device scratch
+    std::map<std::string, std::pair<void*, size_t>> hslots; // named grow-only pinned host scratch
+    int* d_info = nullptr;   // device int (replaces devInfo_d)
+    int* h_info = nullptr;   // pinned host mirror
+    double phase_ms[PH_COUNT] = {};
+    int n_cu = 256;
+    // tunables
+    int trd_nb = 64;
+    int bt_nb = 64;
+    int hemv_blocks = 0;  // 0 = auto
+
+    template <class T> T* scratch(const char* name, size_t count) {
+        return reinterpret_cast<T*>(scratch_bytes(name, count * sizeof(T)));
+    }
+    void* scratch_bytes(const char* name, size_t bytes);
+    void* host_scratch_bytes(const char* name, size_t bytes);
+    void release();
+};
+
+Ctx& ctx();  // lazily created for the current device + calling thread
+
+// host LAPACK plumbing (context.cpp)
+stedc_fn get_dstedc();
+int load_lapack(const char* path);
+void set_host_threads(int n);
+
+// roctx (context.cpp)
+void range_push(const char* name);
+void range_pop();
+
+}  // namespace eig

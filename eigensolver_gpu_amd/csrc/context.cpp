@@ -1,0 +1,242 @@
+// context.cpp -- per-(thread,device) runtime state, host LAPACK binding, roctx ranges.
+// Replaces module eigsolve_vars (eigsolve_vars.F90:25-61) and nvtx_inters
+// (lib_eigsolve/toolbox.F90:25-99) of the reference.
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "../../include/eigsolve_gpu.h"
+#include "common.h"
+
+namespace eig {
+
+namespace {
+thread_local std::map<int, Ctx*> t_ctx;
+
+std::mutex g_lapack_mu;
+void* g_lapack_handle = nullptr;
+stedc_fn g_dstedc = nullptr;
+void (*g_set_threads)(int) = nullptr;
+
+using roctx_push_t = int (*)(const char*);
+using roctx_pop_t = int (*)();
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool g_roctx_tried = false;
+
+void try_roctx() {
+    if (g_roctx_tried) return;
+    g_roctx_tried = true;
+    const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                           "libroctx64.so.4"};
+    for (const char* n : names) {
+        void* h = dlopen(n, RTLD_LAZY | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return;
+    }
+    g_roctx_push = nullptr;
+    g_roctx_pop = nullptr;
+}
+}  // namespace
+
+void* Ctx::scratch_bytes(const char* name, size_t bytes) {
+    auto& s = slots[name];
+    if (s.second < bytes) {
+        if (s.first) {
+            EIG_HIP(hipStreamSynchronize(s1));
+            EIG_HIP(hipFree(s.first));
+        }
+        size_t cap = bytes + bytes / 8 + 256;
+        EIG_HIP(hipMalloc(&s.first, cap));
+        s.second = cap;
+    }
+    return s.first;
+}
+
+void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
+    auto& s = hslots[name];
+    if (s.second < bytes) {
+        if (s.first) EIG_HIP(hipHostFree(s.first));
+        size_t cap = bytes + bytes / 8 + 256;
+        EIG_HIP(hipHostMalloc(&s.first, cap, hipHostMallocDefault));
+        s.second = cap;
+    }
+    return s.first;
+}
+
+void Ctx::release() {
+    for (auto& kv : slots)
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    slots.clear();
+    for (auto& kv : hslots)
+        if (kv.second.first) (void)hipHostFree(kv.second.first);
+    hslots.clear();
+    for (auto& e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (evA) (void)hipEventDestroy(evA);
+    if (evB) (void)hipEventDestroy(evB);
+    if (d_info) (void)hipFree(d_info);
+    if (h_info) (void)hipHostFree(h_info);
+    if (s1) (void)hipStreamDestroy(s1);
+    if (s2) (void)hipStreamDestroy(s2);
+}
+
+Ctx& ctx() {
+    int dev = 0;
+    EIG_HIP(hipGetDevice(&dev));
+    auto it = t_ctx.find(dev);
+    if (it != t_ctx.end()) return *it->second;
+    Ctx* c = new Ctx();
+    c->dev = dev;
+    // blocking streams, like the reference's cudaStreamCreate (eigsolve_vars.F90:50-52)
+    EIG_HIP(hipStreamCreate(&c->s1));
+    EIG_HIP(hipStreamCreate(&c->s2));
+    for (auto& e : c->ev) EIG_HIP(hipEventCreate(&e));
+    EIG_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
+    EIG_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
+    EIG_HIP(hipMalloc((void**)&c->d_info, 64));
+    EIG_HIP(hipHostMalloc((void**)&c->h_info, 64, hipHostMallocDefault));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    if (const char* e = getenv("EIGSOLVE_TRD_NB")) c->trd_nb = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
+    if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
+    if (c->bt_nb < 1 || c->bt_nb > 64) c->bt_nb = 64;
+    t_ctx[dev] = c;
+    return *c;
+}
+
+int load_lapack(const char* path) {
+    std::lock_guard<std::mutex> lk(g_lapack_mu);
+    void* h = nullptr;
+    if (path && *path) {
+        h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) {
+            fprintf(stderr, "eigsolve: cannot dlopen LAPACK library '%s': %s\n", path, dlerror());
+            return -1;
+        }
+    } else {
+        h = dlopen(nullptr, RTLD_NOW);
+    }
+    const char* names[] = {"dstedc_", "scipy_dstedc_", "dstedc", "dstedc_64_", "DSTEDC"};
+    stedc_fn f = nullptr;
+    for (const char* n : names) {
+        f = (stedc_fn)dlsym(h, n);
+        if (f) break;
+    }
+    if (!f) return -1;
+    g_dstedc = f;
+    g_lapack_handle = h;
+    const char* tn[] = {"openblas_set_num_threads", "scipy_openblas_set_num_threads", "openblas_set_num_threads64_",
+                        "MKL_Set_Num_Threads"};
+    g_set_threads = nullptr;
+    for (const char* n : tn) {
+        g_set_threads = (void (*)(int))dlsym(h, n);
+        if (g_set_threads) break;
+    }
+    return 0;
+}
+
+stedc_fn get_dstedc() {
+    if (g_dstedc) return g_dstedc;
+    const char* env = getenv("EIGSOLVE_LAPACK_LIB");
+    if (env && load_lapack(env) == 0) return g_dstedc;
+    if (load_lapack(nullptr) == 0) return g_dstedc;
+    const char* guesses[] = {"liblapack.so.3", "liblapack.so", "libopenblas.so.0", "libopenblas.so", "libmkl_rt.so"};
+    for (const char* g : guesses) {
+        void* h = dlopen(g, RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            dlclose(h);
+            if (load_lapack(g) == 0) return g_dstedc;
+        }
+    }
+    return nullptr;
+}
+
+void set_host_threads(int n) {
+    (void)get_dstedc();
+    if (g_set_threads && n > 0) g_set_threads(n);
+}
+
+void range_push(const char* name) {
+    try_roctx();
+    if (g_roctx_push) {
+        (void)hipDeviceSynchronize();
+        g_roctx_push(name);
+    }
+}
+void range_pop() {
+    try_roctx();
+    if (g_roctx_pop) {
+        (void)hipDeviceSynchronize();
+        g_roctx_pop();
+    }
+}
+
+}  // namespace eig
+
+extern "C" {
+
+int eigsolve_init(void) {
+    try {
+        (void)eig::ctx();
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
+int eigsolve_finalize(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    auto it = eig::t_ctx.find(dev);
+    if (it == eig::t_ctx.end()) return 0;
+    it->second->release();
+    delete it->second;
+    eig::t_ctx.erase(it);
+    return 0;
+}
+
+int eigsolve_set_lapack(const char* path) {
+    if (path && *path) return eig::load_lapack(path);
+    return eig::get_dstedc() ? 0 : -1;
+}
+
+int eigsolve_set_host_threads(int n) {
+    eig::set_host_threads(n);
+    return 0;
+}
+
+int eigsolve_set_option(const char* name, int value) {
+    try {
+        eig::Ctx& c = eig::ctx();
+        std::string s(name ? name : "");
+        if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
+        else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 64) ? 64 : value;
+        else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
+        else return -1;
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
+void eigsolve_range_push(const char* name, int) { eig::range_push(name ? name : "range"); }
+void eigsolve_range_pop(void) { eig::range_pop(); }
+
+int eigsolve_get_phase_times(double* ms, int n) {
+    try {
+        eig::Ctx& c = eig::ctx();
+        int k = n < eig::PH_COUNT ? n : (int)eig::PH_COUNT;
+        for (int i = 0; i < k; ++i) ms[i] = c.phase_ms[i];
+        return k;
+    } catch (...) {
+        return 0;
+    }
+}
+
+const char* eigsolve_version(void) { return "eigensolver_gpu_amd 0.1 (gfx950, fp64 MFMA, wave64)"; }
+}

@@ -1,0 +1,498 @@
+// evd.hip -- standard eigensolver (trd -> host stedc -> back-transform), the generalized
+// drivers, and the C ABI.  Replaces zheevd_gpu / dsyevd_gpu (+ zlarft_gpu, zlarfb_gpu,
+// finish_T_block_kernel; zheevd_gpu.F90:32-279, dsyevd_gpu.F90:32-276) and zhegvdx_gpu /
+// dsygvdx_gpu (zhegvdx_gpu.F90:75-182, dsygvdx_gpu.F90:71-168).
+#include <chrono>
+#include <cstring>
+#include <functional>
+
+#include "../../include/eigsolve_gpu.h"
+#include "trd.h"
+
+namespace eig {
+
+// ---- small kernels ---------------------------------------------------------------------------
+
+// Z(:, 0:m) <- Q(:, 0:m) (real host eigenvectors of T, uploaded as fp64) widened to T.
+template <class T> __global__ void __launch_bounds__(256) widen_kernel(int n, int m, const double* Q, int ldq, T* Z, int ldz) {
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * m) return;
+    int r = (int)(id % n), j = (int)(id / n);
+    Z[(size_t)r + (size_t)j * ldz] = Tr<T>::make(Q[(size_t)r + (size_t)j * ldq], 0.0);
+}
+
+// finish_T_block_kernel (zheevd_gpu.F90:215-279): Tm holds S = V^H V (lower) on entry.
+//   T(r,j) <- -tau(j) S(r,j) (r>j), T(j,j) <- tau(j), then for col = K-2..0:
+//   T(r,col) <- sum_{j=col+1..r} T(j,col) T(r,j), r > col.   Upper part is zeroed.
+template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int K, T* Tm, int ldt, const T* tau) {
+    __shared__ T t[64][65];  // t[col][row]
+    const int tx = threadIdx.x;
+    for (int j = 0; j < K; ++j) {
+        T v = Tr<T>::zero();
+        if (tx < K) {
+            if (tx > j) v = -(tau[j] * Tm[(size_t)tx + (size_t)j * ldt]);
+            else if (tx == j) v = tau[j];
+        }
+        t[j][tx] = v;
+    }
+    __syncthreads();
+    for (int col = K - 2; col >= 0; --col) {
+        T cv = Tr<T>::zero();
+        if (tx > col && tx < K)
+            for (int j = col + 1; j <= tx; ++j) fma_(cv, t[col][j], t[j][tx]);
+        __syncthreads();
+        if (tx > col && tx < K) t[col][tx] = cv;
+        __syncthreads();
+    }
+    for (int j = 0; j < K; ++j)
+        if (tx < K) Tm[(size_t)tx + (size_t)j * ldt] = t[j][tx];
+}
+
+// ---- back-transformation ------------------------------------------------------------------------
+// Q = H_{N-2} ... H_0 applied to C = Z(0:N, 0:m) in blocks of nb2 reflectors, ascending
+// (zheevd_gpu.F90:113-131).  All T factors are built first (they do not depend on C), then each
+// block costs three MFMA launches.  V's bottom square is masked on the fly (unit upper
+// triangular) instead of the reference's stash / zero / restore of A (:154-164, :203-211).
+template <class T>
+static void back_transform(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, const T* tau, T* Z, int ldz, int nb2) {
+    const int k = N - 1;
+    if (k <= 0 || m <= 0) return;
+    if (nb2 > N) nb2 = N;
+    const int nblk = (k + nb2 - 1) / nb2;
+    const int ldt = 64;
+    T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
+    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 64);
+    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 64);
+    for (int b = 0; b < nblk; ++b) {
+        int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
+        const T* V = A + (size_t)(i + 1) * lda;
+        T* Tb = Tall + (size_t)b * ldt * ldt;
+        Operand<T> Va = op_plain(V, lda, 1, 1);  // (r,p) -> conj(V(p,r))
+        Va.mask = M_UNITTRAP; Va.moff = mi - ib;
+        Operand<T> Vb = op_plain(V, lda, 1, 0);  // Bt(j,p) = V(p,j)
+        Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
+        Epi e; e.uplo = 2;
+        gemm_splitk<T>(c, st, ib, ib, mi, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tb, ldt, 256, e);
+        hipLaunchKernelGGL((finish_T_kernel<T>), dim3(1), dim3(64), 0, st, ib, Tb, ldt, tau + i);
+    }
+    EIG_HIP(hipGetLastError());
+    for (int b = 0; b < nblk; ++b) {
+        int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
+        const T* V = A + (size_t)(i + 1) * lda;
+        const T* Tb = Tall + (size_t)b * ldt * ldt;
+        // Wk = C^H V                                  (:193)
+        Operand<T> Ca = op_plain((const T*)Z, ldz, 1, 1);
+        Operand<T> Vb = op_plain(V, lda, 1, 0);
+        Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
+        int tiles = (m + 63) / 64;
+        int want = (2 * c.n_cu + tiles - 1) / tiles;        // splits that fill the chip
+        int kchunk = (mi + want - 1) / want;
+        if (kchunk < 128) kchunk = 128;
+        gemm_splitk<T>(c, st, m, ib, mi, Tr<T>::one(), Ca, Vb, Tr<T>::zero(), Wk, m, kchunk);
+        // Wk2 = Wk T^H                                (:197-198)
+        Operand<T> Tt = op_plain(Tb, ldt, 0, 1);
+        Tt.mask = M_LOWER;
+        gemm<T>(c, st, m, ib, ib, Tr<T>::one(), opA('N', (const T*)Wk, m), Tt, Tr<T>::zero(), Wk2, m);
+        // C -= V Wk2^H                                (:201)
+        Operand<T> Vn = op_plain(V, lda, 0, 0);
+        Vn.mask = M_UNITTRAP; Vn.moff = mi - ib;
+        gemm<T>(c, st, mi, m, ib, Tr<T>::make(-1.0, 0.0), Vn, op_plain((const T*)Wk2, m, 0, 1), Tr<T>::one(), Z, ldz);
+    }
+}
+
+static double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+struct PhaseTimer {
+    Ctx& c;
+    hipStream_t st;
+    explicit PhaseTimer(Ctx& cc) : c(cc), st(cc.s1) {}
+    void begin(int ph) { (void)hipEventRecord(c.ev[2 * ph], st); }
+    void end(int ph) { (void)hipEventRecord(c.ev[2 * ph + 1], st); }
+    void collect(int ph) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c.ev[2 * ph], c.ev[2 * ph + 1]) == hipSuccess) c.phase_ms[ph] += ms;
+    }
+};
+
+// ---- heevd: trd -> host dstedc -> upload wanted vectors -> back-transform -----------------------
+// e_d/tau_d/W_d: device workspace pieces.  e_h[N], Q_h (N x N, ldq), swork/lswork, iwork: host.
+template <class T>
+static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ldz, double* w_d, double* e_d, T* tau_d,
+                      T* W_d, double* w_h, double* e_h, double* Q_h, int ldq, double* swork, long lswork, int* iwork,
+                      int liwork) {
+    hipStream_t st = c.s1;
+    PhaseTimer pt(c);
+    const int m = iu - il + 1;
+    pt.begin(PH_TRD);
+    hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
+    pt.end(PH_TRD);
+    // d, e -> host (zheevd_gpu.F90:85-86)
+    EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    if (N > 1) EIG_HIP(hipMemcpyAsync(e_h, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
+    EIG_HIP(hipStreamSynchronize(st));
+    pt.collect(PH_TRD);
+    double t0 = now_ms();
+    stedc_fn f = get_dstedc();
+    if (!f) {
+        printf(" eigsolve error: no host LAPACK dstedc available (set EIGSOLVE_LAPACK_LIB or call eigsolve_set_lapack)\n");
+        return -1;
+    }
+    int info = 0, n = N, ldqi = ldq;
+    int lw = lswork > 2147483647L ? 2147483647 : (int)lswork;
+    f("I", &n, w_h, e_h, Q_h, &ldqi, swork, &lw, iwork, &liwork, &info, 1);  // :101
+    if (info != 0) {
+        printf(" eigsolve error: dstedc failed! (info=%d)\n", info);
+        return -1;
+    }
+    // wanted vectors (real) and all eigenvalues back to the device (:110-111)
+    double* Qd = c.scratch<double>("evd_Q", (size_t)N * m);
+    EIG_HIP(hipMemcpy2DAsync(Qd, sizeof(double) * N, Q_h + (size_t)(il - 1) * ldq, sizeof(double) * ldq, sizeof(double) * N,
+                             m, hipMemcpyHostToDevice, st));
+    EIG_HIP(hipMemcpyAsync(w_d, w_h, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    size_t tot = (size_t)N * m;
+    hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m, (const double*)Qd, N, Z,
+                       ldz);
+    EIG_HIP(hipStreamSynchronize(st));
+    c.phase_ms[PH_STEDC] += now_ms() - t0;
+    pt.begin(PH_BT);
+    back_transform<T>(c, st, N, m, A, lda, tau_d, Z, ldz, c.bt_nb);
+    pt.end(PH_BT);
+    return 0;
+}
+
+static void clear_phases(Ctx& c) {
+    for (double& v : c.phase_ms) v = 0.0;
+}
+
+// ---- generalized driver -----------------------------------------------------------------------------
+template <class T>
+static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ldz, int il, int iu, double* w_d, double* e_d,
+                       T* tau_d, T* W_d, double* w_h, double* e_h, double* Q_h, int ldq, double* swork, long lswork,
+                       int* iwork, int liwork, T* Z_h, int ldz_h, int skip_host_copy, const char* name) {
+    hipStream_t st = c.s1;
+    PhaseTimer pt(c);
+    clear_phases(c);
+    double t_all = now_ms();
+    const int m = iu - il + 1;
+    // Cholesky of B (zhegvdx_gpu.F90:135-142)
+    pt.begin(PH_POTRF);
+    potrf_upper<T>(c, st, N, B, ldb);
+    pt.end(PH_POTRF);
+    EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    EIG_HIP(hipStreamSynchronize(st));
+    pt.collect(PH_POTRF);
+    if (c.h_info[0] != 0) {
+        printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
+        return -1;
+    }
+    // The reference saves strict-lower(A) in Z here and restores it later (:144-152) because
+    // its gst/td2 overwrite parts of it; this implementation never writes below the diagonal.
+    pt.begin(PH_GST);
+    hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
+    pt.end(PH_GST);
+    int info = heevd_core<T>(c, il, iu, N, A, lda, Z, ldz, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork, lswork, iwork,
+                             liwork);  // :163
+    if (info != 0) return -1;
+    pt.begin(PH_TRSM);
+    trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz);  // :169
+    pt.end(PH_TRSM);
+    pt.begin(PH_D2H);
+    if (!skip_host_copy) {
+        hipError_t e = hipMemcpy2DAsync(Z_h, sizeof(T) * ldz_h, Z, sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            printf(" %s error: hipMemcpy2D failed!\n", name);
+            return -1;
+        }
+    }
+    pt.end(PH_D2H);
+    EIG_HIP(hipStreamSynchronize(st));
+    pt.collect(PH_GST); pt.collect(PH_BT); pt.collect(PH_TRSM); pt.collect(PH_D2H);
+    c.phase_ms[PH_TOTAL] = now_ms() - t_all;
+    return 0;
+}
+
+template <class F> static int guarded(int* info, F&& f) {
+    int r;
+    try {
+        r = f();
+    } catch (const HipFail&) {
+        r = -1;
+    } catch (...) {
+        r = -1;
+    }
+    if (info) *info = r;
+    return r;
+}
+
+template <class T> static int bench_loop(Ctx& c, int reps, double* ms_avg, const std::function<void()>& body) {
+    if (reps < 1) reps = 1;
+    body();  // warm-up
+    EIG_HIP(hipStreamSynchronize(c.s1));
+    EIG_HIP(hipEventRecord(c.ev[0], c.s1));
+    for (int r = 0; r < reps; ++r) body();
+    EIG_HIP(hipEventRecord(c.ev[1], c.s1));
+    EIG_HIP(hipStreamSynchronize(c.s1));
+    float ms = 0.f;
+    EIG_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    if (ms_avg) *ms_avg = (double)ms / reps;
+    return 0;
+}
+}  // namespace eig
+
+using namespace eig;
+
+// (all functions below were declared extern "C" in eigsolve_gpu.h and keep C linkage)
+
+int eigsolve_zhegvdx(int N, void* A_d, int lda, void* B_d, int ldb, void* Z_d, int ldz, int il, int iu, double* w_d,
+                     void* work_d, int lwork, double* rwork_d, int lrwork, void* work_h, int lwork_h, double* rwork_h,
+                     int lrwork_h, int* iwork_h, int liwork_h, void* Z_h, int ldz_h, double* w_h, int* info,
+                     int skip_host_copy) {
+    (void)work_h;
+    return guarded(info, [&]() -> int {
+        const long n = N;
+        // workspace checks, same conditions and wording as zhegvdx_gpu.F90:107-127
+        if (lwork < 2 * 64 * 64 + 65 * n) { printf(" zhegvdx_gpu error: lwork must be at least 2*64*64 + 65*N\n"); return -1; }
+        if (lrwork < n) { printf(" zhegvdx_gpu error: lrwork must be at least N\n"); return -1; }
+        if (lwork_h < n) { printf(" zhegvdx_gpu error: lwork_h must be at least N\n"); return -1; }
+        if (lrwork_h < 1 + 5 * n + 2 * n * n) { printf(" zhegvdx_gpu error: lrwork_h must be at least 1 + 5*N + 2*N*N\n"); return -1; }
+        if (liwork_h < 3 + 5 * n) { printf(" zhegvdx_gpu error: liwork_h must be at least 3 + 5*N\n"); return -1; }
+        if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" zhegvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        Ctx& c = ctx();
+        // carve-up as zheevd_gpu.F90:68-75: tau = work(1:N), e = rwork(1:N), rest of work = panel W
+        cplx* work = (cplx*)work_d;
+        cplx* tau = work;
+        cplx* W = work + n;  // 8192 + 64 N elements >= N * 64
+        double* e_d = rwork_d;
+        double* e_h = rwork_h;            // rwork_h(1:N)
+        double* Q_h = rwork_h + n;        // N x N real eigenvectors of T
+        double* swork = Q_h + n * n;      // 1 + 4N + N^2 for dstedc('I')
+        long lswork = (long)lrwork_h - n - n * n;
+        return hegvdx_core<cplx>(c, N, (cplx*)A_d, lda, (cplx*)B_d, ldb, (cplx*)Z_d, ldz, il, iu, w_d, e_d, tau, W, w_h, e_h,
+                                 Q_h, N, swork, lswork, iwork_h, liwork_h, (cplx*)Z_h, ldz_h, skip_host_copy, "zhegvdx_gpu");
+    });
+}
+
+int eigsolve_dsygvdx(int N, double* A_d, int lda, double* B_d, int ldb, double* Z_d, int ldz, int il, int iu, double* w_d,
+                     double* work_d, int lwork, double* work_h, int lwork_h, int* iwork_h, int liwork_h, double* Z_h,
+                     int ldz_h, double* w_h, int* info, int skip_host_copy) {
+    return guarded(info, [&]() -> int {
+        const long n = N;
+        if (lwork < 2 * 64 * 64 + 66 * n) { printf(" dsygvdx_gpu error: lwork must be at least 2*64*64 + 66*N\n"); return -1; }
+        if (lwork_h < 1 + 6 * n + 2 * n * n) { printf(" dsygvdx_gpu error: lwork_h must be at least 1 + 6*N + 2*N*N\n"); return -1; }
+        if (liwork_h < 3 + 5 * n) { printf(" dsygvdx_gpu error: liwork_h must be at least 3 + 5*N\n"); return -1; }
+        if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" dsygvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        Ctx& c = ctx();
+        // dsyevd_gpu.F90:68-74: e = work(1:N), tau = work(N+1:2N), W = work(2N+1:)
+        double* e_d = work_d;
+        double* tau = work_d + n;
+        double* W = work_d + 2 * n;
+        double* e_h = work_h;                  // work_h(1:N)
+        double* Q_h = work_h + 2 * n;          // N x N, ld N (the reference puts it in Z_h; Z_h then receives the result)
+        double* swork = Q_h + n * n;
+        long lswork = (long)lwork_h - 2 * n - n * n;
+        return hegvdx_core<double>(c, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e_d, tau, W, w_h, e_h, Q_h, N, swork, lswork,
+                                   iwork_h, liwork_h, Z_h, ldz_h, skip_host_copy, "dsygvdx_gpu");
+    });
+}
+
+int eigsolve_zheevd(int il, int iu, int N, void* A_d, int lda, void* Z_d, int ldz, double* w_d, void* work_d, int lwork,
+                    double* rwork_d, int lrwork, void* work_h, int lwork_h, double* rwork_h, int lrwork_h, int* iwork_h,
+                    int liwork_h, void* Z_h, int ldz_h, double* w_h, int* info) {
+    (void)work_h; (void)lwork_h; (void)Z_h; (void)ldz_h;
+    return guarded(info, [&]() -> int {
+        const long n = N;
+        if (lwork < 2 * 64 * 64 + 65 * n || lrwork < n || lrwork_h < 1 + 5 * n + 2 * n * n || liwork_h < 3 + 5 * n) {
+            printf(" zheevd_gpu error: workspace too small\n");
+            return -1;
+        }
+        if (N <= 0 || il < 1 || iu > N || iu < il) return -1;
+        Ctx& c = ctx();
+        clear_phases(c);
+        cplx* work = (cplx*)work_d;
+        int r = heevd_core<cplx>(c, il, iu, N, (cplx*)A_d, lda, (cplx*)Z_d, ldz, w_d, rwork_d, work, work + n, w_h, rwork_h,
+                                 rwork_h + n, N, rwork_h + n + n * n, (long)lrwork_h - n - n * n, iwork_h, liwork_h);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return r;
+    });
+}
+
+int eigsolve_dsyevd(int il, int iu, int N, double* A_d, int lda, double* Z_d, int ldz, double* w_d, double* work_d, int lwork,
+                    double* work_h, int lwork_h, int* iwork_h, int liwork_h, double* Z_h, int ldz_h, double* w_h, int* info) {
+    (void)Z_h; (void)ldz_h;
+    return guarded(info, [&]() -> int {
+        const long n = N;
+        if (lwork < 2 * 64 * 64 + 66 * n || lwork_h < 1 + 6 * n + 2 * n * n || liwork_h < 3 + 5 * n) {
+            printf(" dsyevd_gpu error: workspace too small\n");
+            return -1;
+        }
+        if (N <= 0 || il < 1 || iu > N || iu < il) return -1;
+        Ctx& c = ctx();
+        clear_phases(c);
+        int r = heevd_core<double>(c, il, iu, N, A_d, lda, Z_d, ldz, w_d, work_d, work_d + n, work_d + 2 * n, w_h, work_h,
+                                   work_h + 2 * n, N, work_h + 2 * n + n * n, (long)lwork_h - 2 * n - n * n, iwork_h, liwork_h);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return r;
+    });
+}
+
+int eigsolve_zhegst(int N, void* A_d, int lda, const void* B_d, int ldb, int nb) {
+    (void)nb;
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        build_invU<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
+        hegst_upper<cplx>(c, c.s1, N, (cplx*)A_d, lda, (const cplx*)B_d, ldb);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_dsygst(int N, double* A_d, int lda, const double* B_d, int ldb, int nb) {
+    (void)nb;
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        build_invU<double>(c, c.s1, N, B_d, ldb);
+        hegst_upper<double>(c, c.s1, N, A_d, lda, B_d, ldb);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+
+template <class T> static int hetrd_entry(int N, T* A, int lda, double* d, double* e, T* tau, T* work, int lwork, int nb) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        if (nb <= 0) nb = c.trd_nb;
+        if (nb > 64) nb = 64;
+        T* W = work;
+        if (!W || (long)lwork < (long)N * nb) W = c.scratch<T>("trd_W", (size_t)N * nb);
+        hetrd_upper<T>(c, c.s1, N, A, lda, d, e, tau, W, nb);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_zhetrd(int N, void* A_d, int lda, double* d_d, double* e_d, void* tau_d, void* work_d, int lwork, int nb) {
+    return hetrd_entry<cplx>(N, (cplx*)A_d, lda, d_d, e_d, (cplx*)tau_d, (cplx*)work_d, lwork, nb);
+}
+int eigsolve_dsytrd(int N, double* A_d, int lda, double* d_d, double* e_d, double* tau_d, double* work_d, int lwork, int nb) {
+    return hetrd_entry<double>(N, A_d, lda, d_d, e_d, tau_d, work_d, lwork, nb);
+}
+
+template <class T> static int potrf_entry(int N, T* B, int ldb, int* info_h) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        potrf_upper<T>(c, c.s1, N, B, ldb);
+        EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, c.s1));
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        if (info_h) *info_h = c.h_info[0];
+        return 0;
+    });
+}
+int eigsolve_zpotrf(int N, void* B_d, int ldb, int* info_h) { return potrf_entry<cplx>(N, (cplx*)B_d, ldb, info_h); }
+int eigsolve_dpotrf(int N, double* B_d, int ldb, int* info_h) { return potrf_entry<double>(N, B_d, ldb, info_h); }
+
+template <class T> static int hemv_entry(int n, const T* A, int lda, const T* x, T* y) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        hemv_upper<T>(c, c.s1, n, A, lda, x, y, true);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_zhemv(int n, const void* A_d, int lda, const void* x_d, void* y_d) {
+    return hemv_entry<cplx>(n, (const cplx*)A_d, lda, (const cplx*)x_d, (cplx*)y_d);
+}
+int eigsolve_dsymv(int n, const double* A_d, int lda, const double* x_d, double* y_d) {
+    return hemv_entry<double>(n, A_d, lda, x_d, y_d);
+}
+template <class T> static int hemv_bench_entry(int n, const T* A, int lda, const T* x, T* y, int reps, double* ms) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        return bench_loop<T>(c, reps, ms, [&]() { hemv_upper<T>(c, c.s1, n, A, lda, x, y, false); });
+    });
+}
+int eigsolve_zhemv_bench(int n, const void* A_d, int lda, const void* x_d, void* y_d, int reps, double* ms_avg) {
+    return hemv_bench_entry<cplx>(n, (const cplx*)A_d, lda, (const cplx*)x_d, (cplx*)y_d, reps, ms_avg);
+}
+int eigsolve_dsymv_bench(int n, const double* A_d, int lda, const double* x_d, double* y_d, int reps, double* ms_avg) {
+    return hemv_bench_entry<double>(n, A_d, lda, x_d, y_d, reps, ms_avg);
+}
+
+template <class T> static T scal_from(const double* p) { return Tr<T>::make(p[0], Tr<T>::cx ? p[1] : 0.0); }
+
+template <class T>
+static int gemm_entry(char ta, char tb, int M, int N, int K, const double* alpha, const T* A, int lda, const T* B, int ldb,
+                      const double* beta, T* C, int ldc) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        gemm<T>(c, c.s1, M, N, K, scal_from<T>(alpha), opA(ta, A, lda), opB(tb, B, ldb), scal_from<T>(beta), C, ldc);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_zgemm(char ta, char tb, int M, int N, int K, const double* alpha, const void* A_d, int lda, const void* B_d, int ldb,
+                   const double* beta, void* C_d, int ldc) {
+    return gemm_entry<cplx>(ta, tb, M, N, K, alpha, (const cplx*)A_d, lda, (const cplx*)B_d, ldb, beta, (cplx*)C_d, ldc);
+}
+int eigsolve_dgemm(char ta, char tb, int M, int N, int K, const double* alpha, const double* A_d, int lda, const double* B_d,
+                   int ldb, const double* beta, double* C_d, int ldc) {
+    return gemm_entry<double>(ta, tb, M, N, K, alpha, A_d, lda, B_d, ldb, beta, C_d, ldc);
+}
+template <class T>
+static int gemm_bench_entry(char ta, char tb, int M, int N, int K, const T* A, int lda, const T* B, int ldb, T* C, int ldc,
+                            int reps, double* ms) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        return bench_loop<T>(c, reps, ms, [&]() {
+            gemm<T>(c, c.s1, M, N, K, Tr<T>::one(), opA(ta, A, lda), opB(tb, B, ldb), Tr<T>::zero(), C, ldc);
+        });
+    });
+}
+int eigsolve_zgemm_bench(char ta, char tb, int M, int N, int K, const void* A_d, int lda, const void* B_d, int ldb, void* C_d,
+                         int ldc, int reps, double* ms_avg) {
+    return gemm_bench_entry<cplx>(ta, tb, M, N, K, (const cplx*)A_d, lda, (const cplx*)B_d, ldb, (cplx*)C_d, ldc, reps, ms_avg);
+}
+int eigsolve_dgemm_bench(char ta, char tb, int M, int N, int K, const double* A_d, int lda, const double* B_d, int ldb,
+                         double* C_d, int ldc, int reps, double* ms_avg) {
+    return gemm_bench_entry<double>(ta, tb, M, N, K, A_d, lda, B_d, ldb, C_d, ldc, reps, ms_avg);
+}
+
+template <class T> static int her2k_entry(int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc, int reps, double* ms) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        if (reps > 0) return bench_loop<T>(c, reps, ms, [&]() { her2k_un<T>(c, c.s1, n, k, V, ldv, W, ldw, C, ldc); });
+        her2k_un<T>(c, c.s1, n, k, V, ldv, W, ldw, C, ldc);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_zher2k(int n, int k, const void* V_d, int ldv, const void* W_d, int ldw, void* C_d, int ldc) {
+    return her2k_entry<cplx>(n, k, (const cplx*)V_d, ldv, (const cplx*)W_d, ldw, (cplx*)C_d, ldc, 0, nullptr);
+}
+int eigsolve_dsyr2k(int n, int k, const double* V_d, int ldv, const double* W_d, int ldw, double* C_d, int ldc) {
+    return her2k_entry<double>(n, k, V_d, ldv, W_d, ldw, C_d, ldc, 0, nullptr);
+}
+int eigsolve_zher2k_bench(int n, int k, const void* V_d, int ldv, const void* W_d, int ldw, void* C_d, int ldc, int reps,
+                          double* ms_avg) {
+    return her2k_entry<cplx>(n, k, (const cplx*)V_d, ldv, (const cplx*)W_d, ldw, (cplx*)C_d, ldc, reps < 1 ? 1 : reps, ms_avg);
+}
+int eigsolve_dsyr2k_bench(int n, int k, const double* V_d, int ldv, const double* W_d, int ldw, double* C_d, int ldc, int reps,
+                          double* ms_avg) {
+    return her2k_entry<double>(n, k, V_d, ldv, W_d, ldw, C_d, ldc, reps < 1 ? 1 : reps, ms_avg);
+}
+
+template <class T> static int trsm_entry(int N, int m, const T* U, int ldu, T* Z, int ldz) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        build_invU<T>(c, c.s1, N, U, ldu);
+        trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz);
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        return 0;
+    });
+}
+int eigsolve_ztrsm_lun(int N, int m, const void* U_d, int ldu, void* Z_d, int ldz) {
+    return trsm_entry<cplx>(N, m, (const cplx*)U_d, ldu, (cplx*)Z_d, ldz);
+}
+int eigsolve_dtrsm_lun(int N, int m, const double* U_d, int ldu, double* Z_d, int ldz) {
+    return trsm_entry<double>(N, m, U_d, ldu, Z_d, ldz);
+}

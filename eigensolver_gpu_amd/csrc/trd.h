@@ -1,0 +1,16 @@
+// trd.h -- tridiagonalization layer (internal).
+#pragma once
+#include "blas3.h"
+
+namespace eig {
+
+// Blocked Householder tridiagonalization, uplo='U' (zhetrd_gpu.F90:30-96).  W = N x nb
+// workspace (ld N).  d[N], e[N-1], tau[N-1] on device.
+template <class T>
+void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb);
+
+// y = A x, A Hermitian upper (zhemv_gpu.F90:33-193).  gather=false leaves only the tile
+// partials in scratch (used to time the HBM-bound kernel alone).
+template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather);
+
+}  // namespace eig

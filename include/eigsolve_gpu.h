@@ -1,0 +1,157 @@
+/*
+ * eigsolve_gpu.h -- C ABI of the MI355X-native generalized symmetric/Hermitian-definite
+ * eigensolver (drop-in boundary for NVIDIA/Eigensolver_gpu's dsygvdx_gpu / zhegvdx_gpu).
+ *
+ * Everything here is extern "C", plain pointers and ints: the Fortran modules under
+ * eigensolver_gpu_amd/fortran/ (same module + procedure names and argument order as the
+ * reference) are thin iso_c_binding wrappers over these symbols, and the Python host
+ * mirror (eigensolver_gpu_amd/api.py) binds the same symbols with ctypes.
+ *
+ * Conventions (identical to the reference): column-major, fp64; complex = interleaved
+ * (re,im) doubles = Fortran complex(8); "_d" pointers are DEVICE pointers, "_h" pointers
+ * are HOST pointers (pinned recommended, pageable works); leading dimensions in elements.
+ * Reference citations are relative to /root/reference/lib_eigsolve/.
+ */
+#ifndef EIGSOLVE_GPU_H
+#define EIGSOLVE_GPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime state (replaces module eigsolve_vars, eigsolve_vars.F90:25-61) ------------ */
+
+/* init_eigsolve_gpu (eigsolve_vars.F90:39-59): creates the per-(thread,device) context
+ * (streams, events, scratch arena) for the CURRENT HIP device.  Called lazily by every
+ * entry point (zhegvdx_gpu.F90:131).  Returns 0 on success. */
+int eigsolve_init(void);
+
+/* Releases the calling thread's context for the current device (the reference never frees). */
+int eigsolve_finalize(void);
+
+/* Host LAPACK used for the tridiagonal step (reference: zstedc/dstedc from the linked
+ * LAPACK, zheevd_gpu.F90:101 / dsyevd_gpu.F90:99).  `path` = shared library exporting
+ * dstedc_ (or scipy_dstedc_); NULL -> $EIGSOLVE_LAPACK_LIB, then the process' own symbols.
+ * Returns 0 if a dstedc symbol was resolved. */
+int eigsolve_set_lapack(const char *path);
+
+/* Caps the host LAPACK thread count (OpenBLAS builds only; no-op otherwise). */
+int eigsolve_set_host_threads(int nthreads);
+
+/* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks"};
+ * value<=0 restores the CDNA4 default.  Returns 0 / -1 (unknown name). */
+int eigsolve_set_option(const char *name, int value);
+
+/* nvtxStartRange / nvtxEndRange (lib_eigsolve/toolbox.F90:71-97) -> roctx ranges when
+ * librocprofiler-sdk-roctx is loadable, otherwise no-ops.  Like the reference they
+ * synchronise the device before push and before pop (toolbox.F90:77,94). */
+void eigsolve_range_push(const char *name, int color_id);
+void eigsolve_range_pop(void);
+
+/* Per-phase wall times (ms) of the LAST driver call on this thread/device, measured with
+ * HIP events on the library's stream plus a host clock for the host LAPACK step:
+ * [0] potrf [1] gst [2] trd total [3] host stedc (+ D2H d,e / H2D vectors) [4] back-transform
+ * [5] trsm [6] final D2H copy [7] total.  Returns the number of entries written (<= n). */
+int eigsolve_get_phase_times(double *ms, int n);
+
+/* ---- drivers (the drop-in boundary) -------------------------------------------------- */
+
+/* zhegvdx_gpu (zhegvdx_gpu.F90:75-182).  A x = lambda B x, eigenpairs il..iu (1-based),
+ * upper triangles of A_d,B_d populated.  On exit: B_d = U (Cholesky factor), upper(A_d)
+ * destroyed, strict lower(A_d) preserved, Z_d(:,1:iu-il+1) eigenvectors, w_d(1:N) ALL
+ * eigenvalues ascending (zheevd_gpu.F90:111), Z_h/w_h host copies (Z_h skipped when
+ * skip_host_copy != 0).  Size contract (checked, *info=-1 + message otherwise):
+ * lwork >= 2*64*64+65*N, lrwork >= N, lwork_h >= N, lrwork_h >= 1+5*N+2*N*N,
+ * liwork_h >= 3+5*N; Z_d and Z_h need N columns.  *info = 0 ok / -1 error (bad workspace,
+ * B not positive definite, tridiagonal solver failure, copy failure).  Blocking: results
+ * are valid on return.  Return value == *info. */
+int eigsolve_zhegvdx(int N, void *A_d, int lda, void *B_d, int ldb, void *Z_d, int ldz, int il, int iu,
+                     double *w_d, void *work_d, int lwork, double *rwork_d, int lrwork, void *work_h,
+                     int lwork_h, double *rwork_h, int lrwork_h, int *iwork_h, int liwork_h, void *Z_h,
+                     int ldz_h, double *w_h, int *info, int skip_host_copy);
+
+/* dsygvdx_gpu (dsygvdx_gpu.F90:71-168).  Real analogue; lwork >= 2*64*64+66*N,
+ * lwork_h >= 1+6*N+2*N*N, liwork_h >= 3+5*N. */
+int eigsolve_dsygvdx(int N, double *A_d, int lda, double *B_d, int ldb, double *Z_d, int ldz, int il, int iu,
+                     double *w_d, double *work_d, int lwork, double *work_h, int lwork_h, int *iwork_h,
+                     int liwork_h, double *Z_h, int ldz_h, double *w_h, int *info, int skip_host_copy);
+
+/* ---- stage routines (public module procedures of the reference) ---------------------- */
+
+/* zheevd_gpu / dsyevd_gpu (zheevd_gpu.F90:32-134, dsyevd_gpu.F90:32-132): standard problem,
+ * jobz='V', uplo='U'.  Same workspace carve-up contract as the drivers. */
+int eigsolve_zheevd(int il, int iu, int N, void *A_d, int lda, void *Z_d, int ldz, double *w_d, void *work_d,
+                    int lwork, double *rwork_d, int lrwork, void *work_h, int lwork_h, double *rwork_h,
+                    int lrwork_h, int *iwork_h, int liwork_h, void *Z_h, int ldz_h, double *w_h, int *info);
+int eigsolve_dsyevd(int il, int iu, int N, double *A_d, int lda, double *Z_d, int ldz, double *w_d,
+                    double *work_d, int lwork, double *work_h, int lwork_h, int *iwork_h, int liwork_h,
+                    double *Z_h, int ldz_h, double *w_h, int *info);
+
+/* zhegst_gpu / dsygst_gpu (zhegst_gpu.F90:31-109): itype=1, uplo='U': A <- U^-H A U^-1,
+ * B_d holds U.  nb is accepted for signature compatibility (the recursion picks its own
+ * blocking).  Only the upper triangle of A is read or written. */
+int eigsolve_zhegst(int N, void *A_d, int lda, const void *B_d, int ldb, int nb);
+int eigsolve_dsygst(int N, double *A_d, int lda, const double *B_d, int ldb, int nb);
+
+/* zhetrd_gpu / dsytrd_gpu (zhetrd_gpu.F90:30-96): uplo='U'.  d[N], e[N-1], tau[N-1] device
+ * outputs; reflectors in upper(A) exactly as the reference leaves them (explicit 1 at
+ * A(i-1,i) for the blocked part, e written back only inside the final 32x32 block).
+ * work_d/lwork may be NULL/0 (internal scratch is used); nb<=0 -> default. */
+int eigsolve_zhetrd(int N, void *A_d, int lda, double *d_d, double *e_d, void *tau_d, void *work_d, int lwork,
+                    int nb);
+int eigsolve_dsytrd(int N, double *A_d, int lda, double *d_d, double *e_d, double *tau_d, double *work_d,
+                    int lwork, int nb);
+
+/* Upper Cholesky B = U^H U (replaces cusolverDn?potrf, zhegvdx_gpu.F90:135).  *info_h = 0
+ * or the 1-based index of the first non-positive pivot (LAPACK convention). */
+int eigsolve_zpotrf(int N, void *B_d, int ldb, int *info_h);
+int eigsolve_dpotrf(int N, double *B_d, int ldb, int *info_h);
+
+/* ---- kernel-level entry points (parity tests, micro-benchmarks) ---------------------- */
+
+/* zhemv_gpu / dsymv_gpu (zhemv_gpu.F90:33-193): y = A x, A n x n Hermitian, upper stored.
+ * Unlike the reference kernel y need not be pre-zeroed.  Blocking. */
+int eigsolve_zhemv(int n, const void *A_d, int lda, const void *x_d, void *y_d);
+int eigsolve_dsymv(int n, const double *A_d, int lda, const double *x_d, double *y_d);
+
+/* Times `reps` back-to-back launches of the hemv/symv kernel with HIP events on the
+ * library stream; returns the average ms per launch in *ms_avg (roofline leg of bench.py). */
+int eigsolve_zhemv_bench(int n, const void *A_d, int lda, const void *x_d, void *y_d, int reps, double *ms_avg);
+int eigsolve_dsymv_bench(int n, const double *A_d, int lda, const double *x_d, double *y_d, int reps,
+                         double *ms_avg);
+
+/* C = alpha op(A) op(B) + beta C on the fp64 MFMA tile engine (replaces cublas?gemm_v2 call
+ * sites).  ta/tb in {'N','T','C'}.  alpha/beta: pointer to 1 (d) or 2 (z)
+ * doubles on the host. */
+int eigsolve_zgemm(char ta, char tb, int M, int N, int K, const double *alpha, const void *A_d, int lda,
+                   const void *B_d, int ldb, const double *beta, void *C_d, int ldc);
+int eigsolve_dgemm(char ta, char tb, int M, int N, int K, const double *alpha, const double *A_d, int lda,
+                   const double *B_d, int ldb, const double *beta, double *C_d, int ldc);
+/* Same, timed: average ms over reps launches. */
+int eigsolve_zgemm_bench(char ta, char tb, int M, int N, int K, const void *A_d, int lda, const void *B_d, int ldb,
+                         void *C_d, int ldc, int reps, double *ms_avg);
+int eigsolve_dgemm_bench(char ta, char tb, int M, int N, int K, const double *A_d, int lda, const double *B_d,
+                         int ldb, double *C_d, int ldc, int reps, double *ms_avg);
+
+/* her2k/syr2k, uplo='U', trans='N': C <- C - V W^H - W V^H (the trd trailing update,
+ * zhetrd_gpu.F90:67,82).  C n x n, V,W n x k. */
+int eigsolve_zher2k(int n, int k, const void *V_d, int ldv, const void *W_d, int ldw, void *C_d, int ldc);
+int eigsolve_dsyr2k(int n, int k, const double *V_d, int ldv, const double *W_d, int ldw, double *C_d, int ldc);
+int eigsolve_zher2k_bench(int n, int k, const void *V_d, int ldv, const void *W_d, int ldw, void *C_d, int ldc,
+                          int reps, double *ms_avg);
+int eigsolve_dsyr2k_bench(int n, int k, const double *V_d, int ldv, const double *W_d, int ldw, double *C_d,
+                          int ldc, int reps, double *ms_avg);
+
+/* Z(:,0:m) <- U^-1 Z (cublasZtrsm L,U,N,N, zhegvdx_gpu.F90:169).  U = upper Cholesky factor
+ * as left in B_d by ?potrf above (its inverted diagonal blocks are rebuilt here). */
+int eigsolve_ztrsm_lun(int N, int m, const void *U_d, int ldu, void *Z_d, int ldz);
+int eigsolve_dtrsm_lun(int N, int m, const double *U_d, int ldu, double *Z_d, int ldz);
+
+/* Library version / build info string. */
+const char *eigsolve_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGSOLVE_GPU_H */
