@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the dsygvdx_gpu/zhegvdx_gpu hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N>1: under torchrun, one rank per GPU)
+prints ONE JSON line on rank 0.
+
+Workload (BASELINE.json metric / configs[2], "C3"):  zhegvdx, fp64 complex, N=4096,
+eigenpairs 1..1024, reference input recipe (A = T T^H, B = T' T'^H, test_zhegvdx.F90:28-66),
+lda=ldb=ldz=N, workspaces at the reference's minimum sizes.  A "step" is one full solve through the
+C ABI (potrf -> gst -> trd -> host dstedc -> back-transform -> trsm -> D2H of Z), inputs already
+resident in HBM when the timed region starts (W+K pristine (A,B) pairs are staged beforehand: the
+solver destroys its inputs).  N GPUs = N independent problems per step (QE k-point style, weak
+scaling, no data-path collective); value = problems/s over all ranks.
+
+Extra objects on the same line:
+  roofline      dominant kernel = panel_mv_kernel (hemv + stacked gemv, HBM-bound).  achieved =
+                algorithmic bytes (sum_n s*n(n+1)/2 over the launches of one tridiagonalization,
+                SURVEY.md 8(d)) / HIP-event time of exactly that launch sequence, measured live.
+  roofline_mfma her2k (trd trailing update) and gemm on the fp64 MFMA engine vs 78.6 TFLOP/s.
+  cpu_baseline  LAPACK zhegvx (scipy/OpenBLAS, the routine the reference mirrors and its test
+                driver's CPU case) on the host cores, same recipe, bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F64_PEAK_TF = 78.6    # MI355X datasheet fp64 matrix
+
+
+def gen_pair(n, cplx, seed, device, shift_b=0.0):
+    """Reference recipe on the device (torch is plumbing here: input synthesis only)."""
+    import torch
+    g = torch.Generator(device=device)
+    out = []
+    for k in range(2):
+        g.manual_seed(seed * 7919 + k)
+        re = torch.rand((n, n), generator=g, device=device, dtype=torch.float64)
+        L = torch.tril(re, -1)
+        if cplx:
+            im = torch.rand((n, n), generator=g, device=device, dtype=torch.float64)
+            L = torch.complex(L, torch.tril(im, -1))
+        T = L + L.conj().T + torch.diag(torch.diagonal(re)).to(L.dtype)
+        M = T @ T.conj().T
+        M = 0.5 * (M + M.conj().T)
+        if k == 1 and shift_b:
+            M = M + shift_b * torch.eye(n, device=device, dtype=M.dtype)
+        out.append(M.contiguous())   # Hermitian: row-major == column-major of the conjugate; take conj below
+    # column-major storage of M is the row-major storage of M^T = conj(M) for Hermitian M
+    return torch.conj_physical(out[0]).contiguous(), torch.conj_physical(out[1]).contiguous()
+
+
+def work_model(n, m, cplx):
+    c = 4.0 if cplx else 1.0
+    total = c * ((8.0 / 3.0) * n ** 3 + 3.0 * n * n * m)
+    blas3 = c * (2.0 * n ** 3 + 3.0 * n * n * m)
+    return total, blas3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--real", action="store_true", help="dsygvdx instead of zhegvdx")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=0, help="order of the CPU baseline sample (default: min(n, 2048))")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from eigensolver_gpu_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    cplx = not args.real
+    n, m = args.n, args.m
+    K, W = args.steps, args.warmup
+    cores = os.cpu_count() or 1
+    # each rank's host dstedc gets an equal share of the host cores
+    api.lib()
+    api.set_host_threads(max(1, min(64, cores // max(world, 1))))
+
+    # ---- stage W+K pristine input pairs in HBM ------------------------------------------------
+    A0, B0 = gen_pair(n, cplx, 1000 + rank, dev)
+    pairs = [(A0.clone(), B0.clone()) for _ in range(W + K)]
+    ws = api.Workspace(n, cplx)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(W):
+        info, _ = api.hegvdx(pairs[s][0], pairs[s][1], 1, m, ws)
+        assert info == 0
+    barrier()
+    t0 = time.perf_counter()
+    phases = []
+    for s in range(W, W + K):
+        info, _ = api.hegvdx(pairs[s][0], pairs[s][1], 1, m, ws)
+        assert info == 0
+        phases.append(api.phase_times())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- validity: residual of the last solve against pristine inputs (outside the timed region) ----
+    Z = ws.Z[:m, :]                       # (m, N) row-major == N x m column-major
+    Zc = Z.T                              # N x m view
+    wv = ws.w[:m]
+    Ah, Bh = A0.T, B0.T                   # back to math orientation
+    R = Ah @ Zc - (Bh @ Zc) * wv.to(Zc.dtype)[None, :]
+    resid = float(torch.linalg.norm(R) / torch.linalg.norm(Ah))
+    G = Zc.conj().T @ (Bh @ Zc)
+    bortho = float(torch.linalg.norm(G - torch.eye(m, device=dev, dtype=G.dtype)))
+    del R, G
+
+    # optional result gather over RCCL/xGMI (outside the timed region; north_star: gather only)
+    if world > 1:
+        allw = [torch.empty_like(wv) for _ in range(world)]
+        dist.all_gather(allw, wv.contiguous())
+
+    out = None
+    if rank == 0:
+        total_fl, blas3_fl = work_model(n, m, cplx)
+        ms_step = elapsed * 1e3 / K
+        ph = {k: float(np.median([p[k] for p in phases])) for k in phases[0]}
+        gpu_ms = ph["potrf"] + ph["gst"] + ph["trd"] + ph["backtransform"] + ph["trsm"]
+        out = {
+            "metric": "zhegvdx_n4096_m1024_problems_per_s" if (cplx and n == 4096 and m == 1024) else
+                      "%s_n%d_m%d_problems_per_s" % ("zhegvdx" if cplx else "dsygvdx", n, m),
+            "value": world * K / elapsed,
+            "unit": "problems/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c128" if cplx else "f64",
+            "data": "synthetic (reference recipe A=T*T^H, B=T'*T'^H, uniform[0,1) entries, seeded)",
+            "config": {"workload": "%s N=%d eigenpairs 1..%d, one problem per GPU per step" %
+                       ("zhegvdx" if cplx else "dsygvdx", n, m), "lda": n, "il": 1, "iu": m,
+                       "parallelism": "batch-over-gpus x%d" % world},
+            "ms_per_solve": ms_step,
+            "tflops_total_model": total_fl / (ms_step * 1e-3) * 1e-12,
+            "tflops_gpu_phases": total_fl / (gpu_ms * 1e-3) * 1e-12 if gpu_ms > 0 else None,
+            "phase_ms_median": ph,
+            "residual": resid, "residual_bound_N_eps": n * 2.220446049250313e-16, "b_orthonormality": bortho,
+            "host_cores": cores,
+        }
+
+    # ---- roofline legs (rank 0, N=1 semantics: run on this rank's GPU after the timed region) --------
+    if rank == 0 and not args.no_roofline:
+        s_el = 16 if cplx else 8
+        Asw = pairs[-1][0]
+        r = api.hetrd_mv_sweep(Asw, 0, reps=2)
+        per_launch_ms = r["ms_total"] / r["launches"]
+        per_launch_bytes = r["algo_bytes"] / r["launches"]
+        ach = r["algo_bytes"] / (r["ms_total"] * 1e-3) * 1e-9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hemv_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "kernel": "panel_mv_kernel (hemv+stacked gemv), %d launches of one hetrd N=%d" % (r["launches"], n),
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": traffic, "algo_bytes_per_launch": per_launch_bytes, "avg_launch_us": per_launch_ms * 1e3}
+        # largest single hemv (n = N-1): what the kernel sustains when the operand is at full size
+        x = torch.ones(n, dtype=Asw.dtype, device=dev)
+        ms1 = api.hemv_bench(A0, x, reps=20)
+        out["roofline"]["single_launch_n%d_GBs" % n] = s_el * n * (n + 1) / 2 / (ms1 * 1e-3) * 1e-9
+        # MFMA legs
+        dt = A0.dtype
+        nb = 64
+        V = torch.randn((nb, n), dtype=dt, device=dev)
+        Wm = torch.randn((nb, n), dtype=dt, device=dev)
+        C = A0.clone()
+        msk = api.her2k_bench(V, Wm, C, n, nb, reps=10)
+        cmul = 4.0 if cplx else 1.0
+        fl_her2k = cmul * 2.0 * n * n * nb          # c*2*m^2*k (upper triangle, two products)
+        Bm = torch.randn((n, n), dtype=dt, device=dev)
+        Cm = torch.empty((n, n), dtype=dt, device=dev)
+        msg = api.gemm_bench("N", "N", n, n, n, A0, n, Bm, n, Cm, n, reps=3)
+        fl_gemm = cmul * 2.0 * n ** 3
+        blas3_ms = ph["potrf"] + ph["gst"] + ph["backtransform"] + ph["trsm"]
+        out["roofline_mfma"] = {
+            "bound": "mfma", "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
+            "her2k_k64": {"achieved": fl_her2k / (msk * 1e-3) * 1e-12, "frac": fl_her2k / (msk * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msk},
+            "gemm_nn": {"achieved": fl_gemm / (msg * 1e-3) * 1e-12, "frac": fl_gemm / (msg * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msg},
+            "blas3_phases_in_solve": {"achieved": (cmul * ((4.0 / 3.0) * n ** 3 + 3.0 * n * n * m)) / (blas3_ms * 1e-3) * 1e-12 if blas3_ms > 0 else None,
+                                      "note": "potrf+gst+back-transform+trsm model flops / their HIP-event time"},
+        }
+        del V, Wm, C, Bm, Cm
+
+    # ---- CPU baseline (rank 0 only, bounded sample) --------------------------------------------------
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        import scipy.linalg as sl
+        cn = args.cpu_n or min(n, 2048)
+        cm = max(1, cn * m // n)
+        Ac, Bc = gen_pair(cn, cplx, 4242, dev)
+        Ah_np = Ac.T.cpu().numpy()
+        Bh_np = Bc.T.cpu().numpy()
+        t1 = time.perf_counter()
+        wc, Zc_np = sl.eigh(Ah_np, Bh_np, subset_by_index=[0, cm - 1], driver="gvx")
+        tc = time.perf_counter() - t1
+        try:
+            from threadpoolctl import threadpool_info
+            nth = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            nth = cores
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "problems/s", "cores": nth, "kind": "port",
+                               "sample": "LAPACK %s (scipy %s / OpenBLAS) N=%d eigenpairs 1..%d, same recipe, one timed call; "
+                                         "this is the routine the reference mirrors (README.md:19-20) and what its test driver "
+                                         "times on the CPU" % ("zhegvx" if cplx else "dsygvx", __import__("scipy").__version__, cn, cm),
+                               "ms": tc * 1e3}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ EXPORTS = [
     "eigsolve_zpotrf", "eigsolve_dpotrf", "eigsolve_zhemv", "eigsolve_dsymv", "eigsolve_zhemv_bench",
     "eigsolve_dsymv_bench", "eigsolve_zgemm", "eigsolve_dgemm", "eigsolve_zgemm_bench", "eigsolve_dgemm_bench",
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
-    "eigsolve_dtrsm_lun", "eigsolve_version",
+    "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
 ]
 
 
@@ -333,3 +333,18 @@ def trsm_lun(U_d, Z_d, m):
     name = "eigsolve_ztrsm_lun" if _pre(Z_d) == "z" else "eigsolve_dtrsm_lun"
     rc = getattr(lib(), name)(c_int(N), c_int(m), _p(U_d), c_int(U_d.shape[1]), _p(Z_d), c_int(Z_d.shape[1]))
     assert rc == 0
+
+
+def hetrd_mv_sweep(A_d, nb=0, reps=1):
+    """Roofline leg: the panel mat-vec kernels of one full ?hetrd, back to back.
+    Returns dict(ms_total, launches, algo_bytes).  Destroys the numerical content of A_d."""
+    _sync()
+    N = A_d.shape[0]
+    ms = ctypes.c_double(0)
+    nl = ctypes.c_long(0)
+    by = ctypes.c_double(0)
+    name = "eigsolve_zhetrd_mv_sweep" if _pre(A_d) == "z" else "eigsolve_dsytrd_mv_sweep"
+    rc = getattr(lib(), name)(c_int(N), _p(A_d), c_int(A_d.shape[1]), c_int(nb), c_int(reps), ctypes.byref(ms),
+                              ctypes.byref(nl), ctypes.byref(by))
+    assert rc == 0
+    return {"ms_total": ms.value, "launches": nl.value, "algo_bytes": by.value}

@@ -496,3 +496,34 @@ int eigsolve_ztrsm_lun(int N, int m, const void* U_d, int ldu, void* Z_d, int ld
 int eigsolve_dtrsm_lun(int N, int m, const double* U_d, int ldu, double* Z_d, int ldz) {
     return trsm_entry<double>(N, m, U_d, ldu, Z_d, ldz);
 }
+
+template <class T> static int mv_sweep_entry(int N, T* A, int lda, int nb, int reps, double* ms_total, long* nlaunch, double* bytes) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        if (nb <= 0) nb = c.trd_nb;
+        T* W = c.scratch<T>("trd_W", (size_t)N * 64);
+        double* e = c.scratch<double>("sweep_e", (size_t)N + 8);
+        T* tau = c.scratch<T>("sweep_tau", (size_t)N + 8);
+        EIG_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)N * 64, c.s1));
+        long nl = 0; double by = 0;
+        hetrd_mv_sweep<T>(c, c.s1, N, A, lda, W, nb, e, tau, &nl, &by);  // warm-up
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        if (reps < 1) reps = 1;
+        EIG_HIP(hipEventRecord(c.ev[0], c.s1));
+        for (int r = 0; r < reps; ++r) hetrd_mv_sweep<T>(c, c.s1, N, A, lda, W, nb, e, tau, &nl, &by);
+        EIG_HIP(hipEventRecord(c.ev[1], c.s1));
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        float ms = 0.f;
+        EIG_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        if (ms_total) *ms_total = (double)ms / reps;
+        if (nlaunch) *nlaunch = nl;
+        if (bytes) *bytes = by;
+        return 0;
+    });
+}
+int eigsolve_zhetrd_mv_sweep(int N, void* A_d, int lda, int nb, int reps, double* ms_total, long* nlaunch, double* algo_bytes) {
+    return mv_sweep_entry<cplx>(N, (cplx*)A_d, lda, nb, reps, ms_total, nlaunch, algo_bytes);
+}
+int eigsolve_dsytrd_mv_sweep(int N, double* A_d, int lda, int nb, int reps, double* ms_total, long* nlaunch, double* algo_bytes) {
+    return mv_sweep_entry<double>(N, A_d, lda, nb, reps, ms_total, nlaunch, algo_bytes);
+}

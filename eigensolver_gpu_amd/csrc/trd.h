@@ -13,4 +13,8 @@ void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double
 // partials in scratch (used to time the HBM-bound kernel alone).
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather);
 
+// Launches only the panel mat-vec kernels of a full tridiagonalization (bench.py roofline leg).
+template <class T>
+void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes);
+
 }  // namespace eig

@@ -493,7 +493,7 @@ template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N) {
 
 template <class T>
 static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np, int nb, T* A, int lda, double* e, T* tau,
-                        T* W, int ldw) {
+                        T* W, int ldw, bool mv_only = false, long* nlaunch = nullptr, double* algo_bytes = nullptr) {
     PanelArgs<T> a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = e; a.tau = tau;
     a.xbuf = sc.xbuf; a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp; a.NP = sc.NP; a.alphaSlot = sc.alphaSlot;
@@ -504,7 +504,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         a.i = i;
         a.gh = gh_prev; a.nchunk = nchunk_prev;
         int gA = (i + 1 + 63) / 64;
-        hipLaunchKernelGGL((panel_row_kernel<T>), dim3(gA), dim3(256), 0, st, a, do_finish, do_update);
+        if (!mv_only) hipLaunchKernelGGL((panel_row_kernel<T>), dim3(gA), dim3(256), 0, st, a, do_finish, do_update);
         if (last) break;
         // mat-vec for column i (v has i entries)
         int n = i;
@@ -514,6 +514,8 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         int gg = (2 * npo * nchunk + 3) / 4;
         a.nblkA = gA; a.gh = gh; a.nchunk = nchunk;
         hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(256), 0, st, a, 0);
+        if (nlaunch) ++*nlaunch;
+        if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
         gh_prev = gh; nchunk_prev = nchunk;
     }
     EIG_HIP(hipGetLastError());
@@ -545,6 +547,30 @@ void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double
     EIG_HIP(hipGetLastError());
 }
 
+// Roofline leg: the exact sequence of panel_mv_kernel launches of a full tridiagonalization
+// (same grids, same panel state layout, row kernels and her2k skipped; A is left numerically
+// meaningless).  Returns launches and algorithmic bytes sum_n s*n(n+1)/2.
+template <class T>
+void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes) {
+    if (nb <= 0 || nb > NBMAX) nb = NBMAX;
+    TrdScratch<T> sc = trd_scratch<T>(c, N);
+    std::vector<double> ones((size_t)((N + HT - 1) / HT) + 64, 1.0);
+    EIG_HIP(hipMemcpyAsync(sc.NP, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    T one = Tr<T>::one();
+    EIG_HIP(hipMemcpyAsync(sc.alphaSlot, &one, sizeof(T), hipMemcpyHostToDevice, st));
+    EIG_HIP(hipMemcpyAsync(sc.xbuf, A, sizeof(T) * N, hipMemcpyDeviceToDevice, st));
+    EIG_HIP(hipStreamSynchronize(st));
+    *nlaunch = 0; *algo_bytes = 0.0;
+    const int nx = TD;
+    int np = N;
+    while (np - nb >= nx) {
+        latrd_panel(c, st, sc, np, nb, A, lda, e, tau, W, N, true, nlaunch, algo_bytes);
+        np -= nb;
+    }
+    int nbr = np - nx;
+    if (nbr > 0) latrd_panel(c, st, sc, np, nbr, A, lda, e, tau, W, N, true, nlaunch, algo_bytes);
+}
+
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather) {
     if (n <= 0) return;
     TrdScratch<T> sc = trd_scratch<T>(c, n);
@@ -563,6 +589,8 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
 
 template void hetrd_upper<double>(Ctx&, hipStream_t, int, double*, int, double*, double*, double*, double*, int);
 template void hetrd_upper<cplx>(Ctx&, hipStream_t, int, cplx*, int, double*, double*, cplx*, cplx*, int);
+template void hetrd_mv_sweep<double>(Ctx&, hipStream_t, int, double*, int, double*, int, double*, double*, long*, double*);
+template void hetrd_mv_sweep<cplx>(Ctx&, hipStream_t, int, cplx*, int, cplx*, int, double*, cplx*, long*, double*);
 template void hemv_upper<double>(Ctx&, hipStream_t, int, const double*, int, const double*, double*, bool);
 template void hemv_upper<cplx>(Ctx&, hipStream_t, int, const cplx*, int, const cplx*, cplx*, bool);
 

@@ -121,6 +121,17 @@ int eigsolve_zhemv_bench(int n, const void *A_d, int lda, const void *x_d, void 
 int eigsolve_dsymv_bench(int n, const double *A_d, int lda, const double *x_d, double *y_d, int reps,
                          double *ms_avg);
 
+/* Roofline leg of bench.py: launches, back to back on the library stream, exactly the sequence
+ * of panel mat-vec kernels (hemv + stacked gemv, the HBM-bound kernel) that one ?hetrd of order N
+ * issues -- same grids and arguments, the row kernels and her2k updates skipped, so A_d is left
+ * numerically meaningless.  *ms_total = HIP-event time of one sweep (average over reps),
+ * *nlaunch = kernel launches per sweep, *algo_bytes = sum over launches of s*n(n+1)/2
+ * (SURVEY.md 8(d)).  Host clock / events only; results valid on return. */
+int eigsolve_zhetrd_mv_sweep(int N, void *A_d, int lda, int nb, int reps, double *ms_total, long *nlaunch,
+                             double *algo_bytes);
+int eigsolve_dsytrd_mv_sweep(int N, double *A_d, int lda, int nb, int reps, double *ms_total, long *nlaunch,
+                             double *algo_bytes);
+
 /* C = alpha op(A) op(B) + beta C on the fp64 MFMA tile engine (replaces cublas?gemm_v2 call
  * sites).  ta/tb in {'N','T','C'}.  alpha/beta: pointer to 1 (d) or 2 (z)
  * doubles on the host. */

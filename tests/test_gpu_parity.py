@@ -1,0 +1,373 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (1) the CPU oracle on the same seeded inputs, (2) the committed LAPACK golden fixtures,
+and (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (fp64, stated per north_star / SURVEY.md 8(c)):
+  * stage outputs (potrf, hegst):  |gpu - oracle|_max <= 200 * N * eps * |reference|_max;
+    hetrd d/e: <= 200 * N * eps * ||A||_2 (backward-error scale; oracle nb=32 vs device nb=64)
+  * end-to-end, well-conditioned family (B += N*I):  residual ||AZ - BZ diag(w)||_F / ||A||_F <= N*eps,
+    eigenvalue l2 error (reference's compare(), test_driver/toolbox.F90:36-83) <= 1e-12
+  * end-to-end, reference recipe (cond(B) ~ 1e6..1e10):  residual <= N*eps as well (measured ~1e-16),
+    eigenvalues within 10x of LAPACK's own gvd-vs-gvx spread (<= 1e-8), |Z| l2 error <= 1e-5.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+EPS = np.finfo(np.float64).eps
+GOLD = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    torch.cuda.set_device(0)
+    import oracle
+    from eigensolver_gpu_amd import api
+    api.lib()  # fails loudly if the HIP library is missing
+    return torch, oracle, api
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rnd(rng, cplx, *shape):
+    x = rng.standard_normal(shape)
+    if cplx:
+        x = x + 1j * rng.standard_normal(shape)
+    return np.asfortranarray(x.astype(np.complex128 if cplx else np.float64))
+
+
+# ---------------------------------------------------------------------------------------------
+# kernel level
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 200, 777])
+def test_hemv_vs_oracle(env, cplx, n):
+    """zhemv_gpu / dsymv_gpu: upper triangle only is read; lower part is poisoned with NaN."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n)
+    A = oracle.gen_spd(n, 10 + n, cplx)
+    x = rnd(rng, cplx, n)
+    Au = np.triu(A).copy()
+    Au[np.tril_indices(n, -1)] = np.nan
+    y = api.hemv(api.to_device(Au), torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = oracle.herm_from_upper(A) @ x
+    assert rel(y, ref) <= 50 * n * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_hemv_is_deterministic(env, cplx):
+    """No atomics anywhere: two runs are bit-identical (the reference's atomicadd path is not)."""
+    torch, oracle, api = env
+    n = 1500
+    rng = np.random.default_rng(1)
+    A = api.to_device(np.triu(oracle.gen_spd_fast(n, 3, cplx)))
+    x = torch.from_numpy(rnd(rng, cplx, n)).cuda()
+    y1 = api.hemv(A, x).cpu().numpy()
+    y2 = api.hemv(A, x).cpu().numpy()
+    assert np.array_equal(y1, y2)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("C", "N"), ("N", "C"), ("T", "T"), ("T", "N")])
+@pytest.mark.parametrize("dims", [(1, 1, 1), (64, 64, 64), (65, 33, 17), (200, 130, 300), (129, 257, 70)])
+def test_gemm_vs_numpy(env, cplx, ta, tb, dims):
+    """fp64 MFMA tile engine vs numpy; asymmetric random operands catch transposed writes."""
+    torch, oracle, api = env
+    M, N, K = dims
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rnd(rng, cplx, M, K) if ta == "N" else rnd(rng, cplx, K, M)
+    B = rnd(rng, cplx, K, N) if tb == "N" else rnd(rng, cplx, N, K)
+    C = rnd(rng, cplx, M, N)
+    f = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    al, be = ((0.7 - 0.2j), (0.3 + 0.1j)) if cplx else (0.7, 0.3)
+    ref = al * (f[ta](A) @ f[tb](B)) + be * C
+    Cd = api.to_device(C)
+    api.gemm(ta, tb, M, N, K, al, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], be, Cd, M)
+    assert rel(api.to_host(Cd), ref) <= 20 * K * EPS
+    # beta = 0 must not propagate NaNs from C
+    Cn = np.full_like(C, np.nan)
+    Cd = api.to_device(Cn)
+    api.gemm(ta, tb, M, N, K, 1.0, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], 0.0, Cd, M)
+    assert rel(api.to_host(Cd), f[ta](A) @ f[tb](B)) <= 20 * K * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,k", [(1, 1), (64, 64), (100, 32), (333, 64), (130, 7)])
+def test_her2k_vs_numpy(env, cplx, n, k):
+    """trailing update zhetrd_gpu.F90:67: upper only, real diagonal, lower untouched."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n + k)
+    V, W = rnd(rng, cplx, n, k), rnd(rng, cplx, n, k)
+    C = oracle.gen_spd(n, 3, cplx)
+    Cin = np.triu(C).copy()
+    Cin[np.tril_indices(n, -1)] = 7.5
+    Cd = api.to_device(Cin)
+    api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+    got = api.to_host(Cd)
+    ref = C - V @ W.conj().T - W @ V.conj().T
+    assert rel(np.triu(got), np.triu(ref)) <= 50 * k * EPS
+    assert np.all(got[np.tril_indices(n, -1)] == 7.5)
+    if cplx:
+        assert np.all(got.diagonal().imag == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# stage level vs oracle and vs golden LAPACK fixtures
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 31, 64, 65, 129, 300])
+def test_potrf_and_trsm_vs_oracle(env, cplx, n):
+    torch, oracle, api = env
+    B = oracle.gen_spd(n, 2000 + n, cplx, shift=float(n))
+    Bin = np.triu(B).copy()
+    Bin[np.tril_indices(n, -1)] = np.nan  # strict lower is never referenced
+    Bd = api.to_device(Bin)
+    assert api.potrf(Bd) == 0
+    Uo, io = oracle.potrf_upper(B)
+    assert io == 0
+    assert rel(np.triu(api.to_host(Bd)), np.triu(Uo)) <= 100 * n * EPS
+    rng = np.random.default_rng(n)
+    Z = rnd(rng, cplx, n, max(1, n // 3))
+    Zd = api.to_device(Z)
+    api.trsm_lun(Bd, Zd, Z.shape[1])
+    assert rel(api.to_host(Zd), np.linalg.solve(np.triu(Uo), Z)) <= 1e3 * n * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_potrf_reports_first_bad_pivot(env, cplx):
+    torch, oracle, api = env
+    n = 150
+    B = oracle.gen_spd(n, 7, cplx, shift=float(n))
+    B[100, 100] = -5.0
+    info = api.potrf(api.to_device(np.triu(B)))
+    _, io = oracle.potrf_upper(B)
+    assert info == io == 101
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_stages_vs_golden(env, golden_dir, name):
+    """potrf -> hegst -> hetrd against the committed LAPACK outputs (tests/golden/*.npz)."""
+    torch, oracle, api = env
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = g["A"].shape[0]
+    Bd = api.to_device(g["B"])
+    assert api.potrf(Bd) == 0
+    assert rel(np.triu(api.to_host(Bd)), g["U"]) <= 200 * n * EPS
+    Ad = api.to_device(g["A"])
+    api.hegst(Ad, Bd)
+    C = api.to_host(Ad)
+    scale = np.abs(g["C"]).max()
+    assert np.abs(np.triu(C) - g["C"]).max() <= 1e-9 * scale
+    assert np.all(np.tril(C, -1) == 0)  # nothing below the diagonal is ever written
+    Cd = api.to_device(g["C"])
+    d, e, tau = api.hetrd(Cd)
+    tol = 200 * n * EPS * scale
+    assert np.abs(d.cpu().numpy() - g["d"]).max() <= tol
+    assert np.abs(e.cpu().numpy() - g["e"]).max() <= tol
+    assert np.abs(tau.cpu().numpy() - g["tau"]).max() <= 1e-9
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [1, 2, 17, 32, 33, 64, 96, 97, 200, 411])
+@pytest.mark.parametrize("nb", [0, 32, 5])
+@pytest.mark.parametrize("fam", ["wc", "ref"])
+def test_hetrd_vs_oracle(env, cplx, n, nb, fam):
+    """d, e, tau and the stored reflectors against the reference-structured oracle (nb=32).
+    d/e are compared on the backward-error scale ||A||_2 (the device blocking, nb=64, sums in a
+    different order).  tau and V are forward quantities: for the reference recipe ("ref", graded
+    spectrum) the last reflectors act on a trailing block whose norm is ~1e-4 ||A||, so their
+    forward error is amplified accordingly -> tight tolerance only on the shifted family."""
+    torch, oracle, api = env
+    if nb == 5 and n > 100:
+        pytest.skip("small-nb case only on small matrices")
+    A = oracle.gen_spd(n, 500 + n, cplx, shift=float(n) if fam == "wc" else 0.0)
+    Ain = np.triu(A).copy()
+    Ain[np.tril_indices(n, -1)] = -3.25
+    Ad = api.to_device(Ain)
+    d, e, tau = api.hetrd(Ad, nb)
+    Ao, do, eo, tauo = oracle.hetrd(np.triu(A), nb=32)
+    s = max(np.linalg.norm(oracle.herm_from_upper(A), 2), 1e-300)
+    tol = 200 * max(n, 8) * EPS
+    ftol = 1e-7 if fam == "wc" else 1e-6  # forward error of reflectors (a wrong layout or sign gives O(1))
+    assert np.abs(d.cpu().numpy() - do).max() / s <= tol
+    got = api.to_host(Ad)
+    if n > 1:
+        assert np.abs(e.cpu().numpy() - eo).max() / s <= tol
+        assert np.abs(tau.cpu().numpy() - tauo).max() <= ftol
+        assert rel(np.triu(got, 1), np.triu(Ao, 1)) <= ftol
+    assert np.all(got[np.tril_indices(n, -1)] == -3.25)  # strict lower(A) preserved
+    for j in range(33, n):  # blocked part keeps the explicit 1 (zhetrd_gpu.F90:92)
+        assert got[j - 1, j] == 1.0
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [40, 130, 300])
+def test_hetrd_reconstruction(env, cplx, n):
+    """Backward check independent of any other implementation: Q^H A Q = T (Q = H_{n-2}...H_0) rebuilt from
+    the reflectors the device left in upper(A) (the layout the back-transform relies on)."""
+    torch, oracle, api = env
+    A = oracle.gen_spd(n, 900 + n, cplx)
+    Ad = api.to_device(np.triu(A))
+    d, e, tau = api.hetrd(Ad)
+    V = api.to_host(Ad)
+    d, e, tau = d.cpu().numpy(), e.cpu().numpy(), tau.cpu().numpy()
+    H = oracle.herm_from_upper(A)
+    Q = np.eye(n, dtype=H.dtype)
+    for j in range(n - 1):
+        v = np.zeros(n, dtype=H.dtype)
+        v[:j] = V[:j, j + 1]
+        v[j] = 1.0
+        Q = (np.eye(n, dtype=H.dtype) - tau[j] * np.outer(v, v.conj())) @ Q   # Q = H_{n-2} ... H_0
+    Tm = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
+    assert np.abs(Q.conj().T @ H @ Q - Tm).max() <= 50 * n * EPS * np.linalg.norm(H, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# end to end
+# ---------------------------------------------------------------------------------------------
+def run_driver(api, A, B, il, iu, **kw):
+    info, ws = api.hegvdx(api.to_device(A), api.to_device(B), il, iu, **kw)
+    n = A.shape[0]
+    m = iu - il + 1
+    return info, ws, ws.w_h.numpy()[:n].copy(), np.asfortranarray(api.to_host(ws.Z_h, n, m)).copy()
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_hegvdx_vs_golden(env, golden_dir, name):
+    """The reference's own acceptance test (compare() against LAPACK ?hegvd,
+    test_zhegvdx.F90:297-299) on the committed fixtures, plus residual / B-orthonormality."""
+    torch, oracle, api = env
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = g["A"].shape[0]
+    m = max(1, n // 4)
+    info, ws, w, Z = run_driver(api, g["A"], g["B"], 1, m)
+    assert info == 0
+    wc = name.endswith("wc")
+    assert oracle.compare_1d(g["w"], w)[0] <= (1e-13 if wc else 1e-8)
+    assert oracle.compare_abs2d(g["Zabs"][:, :m].astype(Z.dtype), Z)[0] <= (1e-10 if wc else 1e-5)
+    assert oracle.residual(g["A"], g["B"], w, Z) <= n * EPS
+    assert oracle.b_orthonormality(g["B"], Z) <= (1e-12 if wc else 1e-9)
+    # device copies agree with the host copies
+    assert np.array_equal(ws.w.cpu().numpy(), ws.w_h.numpy())
+    assert np.array_equal(api.to_host(ws.Z, n, m), Z)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,il,iu", [(1, 1, 1), (2, 1, 2), (40, 1, 40), (100, 1, 25), (257, 1, 64), (130, 5, 12)])
+def test_hegvdx_vs_oracle(env, cplx, n, il, iu):
+    torch, oracle, api = env
+    A = oracle.gen_spd(n, 1000 + n, cplx)
+    B = oracle.gen_spd(n, 2000 + n, cplx, shift=float(n))
+    Ain = np.triu(A).copy()
+    Ain[np.tril_indices(n, -1)] = 11.0
+    info, ws, w, Z = run_driver(api, Ain, np.triu(B), il, iu)
+    wo, Zo, _, Uo, io = oracle.hegvdx(A, B, il, iu)
+    assert info == 0 and io == 0
+    assert oracle.compare_1d(wo, w)[0] <= 1e-12            # all N eigenvalues (zheevd_gpu.F90:111)
+    assert oracle.compare_abs2d(Zo, Z)[0] <= 1e-8
+    assert oracle.residual(A, B, w[il - 1:iu], Z) <= max(n, 4) * EPS
+    # contract on the inputs: B <- U, strict lower(A) preserved
+    assert rel(np.triu(api.to_host(api.to_device(np.triu(B)))), np.triu(B)) == 0
+    Ad, Bd = api.to_device(Ain), api.to_device(np.triu(B))
+    info2, _ = api.hegvdx(Ad, Bd, il, iu, ws=ws)
+    assert info2 == 0
+    assert rel(np.triu(api.to_host(Bd)), np.triu(Uo)) <= 100 * n * EPS
+    assert np.all(api.to_host(Ad)[np.tril_indices(n, -1)] == 11.0)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_reference_recipe_ill_conditioned(env, cplx):
+    """Reference recipe without shift (cond(B) ~ 1e8): accuracy judged like the reference does,
+    against LAPACK, with the spread LAPACK itself shows."""
+    torch, oracle, api = env
+    import scipy.linalg as sl
+    n, m = 384, 96
+    A = oracle.gen_spd_fast(n, 1384, cplx)
+    B = oracle.gen_spd_fast(n, 2384, cplx)
+    info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
+    assert info == 0
+    wl, Zl = sl.eigh(A, B, driver="gvd")
+    assert oracle.compare_1d(wl, w)[0] <= 1e-8
+    res_gpu = oracle.residual(A, B, w, Z)
+    res_lapack = oracle.residual(A, B, wl, Zl[:, :m])
+    assert res_gpu <= max(n * EPS, 4 * res_lapack)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_error_paths(env, cplx):
+    """info = -1 on short workspaces and on a non-positive-definite B (zhegvdx_gpu.F90:107-142)."""
+    torch, oracle, api = env
+    n = 48
+    A = oracle.gen_spd(n, 1, cplx)
+    B = oracle.gen_spd(n, 2, cplx, shift=1.0)
+    ws = api.Workspace(n, cplx)
+    ws.lwork -= 1
+    info, _ = api.hegvdx(api.to_device(A), api.to_device(B), 1, 4, ws=ws)
+    assert info == -1
+    ws = api.Workspace(n, cplx)
+    ws.liwork_h = n  # the reference only checks >= N here; dstedc needs 3+5N -> still an error
+    info, _ = api.hegvdx(api.to_device(A), api.to_device(B), 1, 4, ws=ws)
+    assert info == -1
+    Bbad = B.copy()
+    Bbad[10, 10] = -1.0
+    info, _ = api.hegvdx(api.to_device(A), api.to_device(np.triu(Bbad)), 1, 4)
+    assert info == -1
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_skip_host_copy_and_pageable_buffers(env, cplx):
+    torch, oracle, api = env
+    n, m = 96, 24
+    A = oracle.gen_spd(n, 11, cplx)
+    B = oracle.gen_spd(n, 12, cplx, shift=float(n))
+    ws = api.Workspace(n, cplx, pinned=False)
+    ws.Z_h.zero_()
+    info, ws = api.hegvdx(api.to_device(A), api.to_device(B), 1, m, ws=ws, skip_host_copy=True)
+    assert info == 0
+    assert float(ws.Z_h.abs().max()) == 0.0          # host copy skipped
+    Z = np.asfortranarray(api.to_host(ws.Z, n, m))
+    assert oracle.residual(A, B, ws.w.cpu().numpy(), Z) <= n * EPS
+
+
+def test_run_to_run_bit_identical(env):
+    torch, oracle, api = env
+    n, m = 200, 50
+    A = oracle.gen_spd(n, 21, True)
+    B = oracle.gen_spd(n, 22, True, shift=float(n))
+    outs = []
+    for _ in range(2):
+        info, ws, w, Z = run_driver(api, A, B, 1, m)
+        assert info == 0
+        outs.append((w, Z))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties (the oracle is too slow here)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [("C2", False, 2048, 512), ("C3", True, 4096, 1024)])
+def test_full_size_properties(env, cfg):
+    """configs[1] and configs[2]: residual, B-orthonormality, ascending eigenvalues, trace identity
+    sum(w) = trace(B^-1 A), and agreement of the wanted eigenvalues with LAPACK ?hegvx on the host."""
+    torch, oracle, api = env
+    import scipy.linalg as sl
+    name, cplx, n, m = cfg
+    A = oracle.gen_spd_fast(n, 1000 + n, cplx)
+    B = oracle.gen_spd_fast(n, 2000 + n, cplx, shift=float(n))
+    info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
+    assert info == 0
+    assert np.all(np.diff(w) >= 0)
+    assert oracle.residual(A, B, w, Z) <= n * EPS
+    assert oracle.b_orthonormality(B, Z) <= 1e-10
+    tr = np.trace(np.linalg.solve(B, A)).real
+    assert abs(w.sum() - tr) <= 1e-9 * abs(tr)
+    wl = sl.eigh(A, B, eigvals_only=True, subset_by_index=[0, m - 1], driver="gvx")
+    assert oracle.compare_1d(wl, w[:m])[0] <= 1e-12
