@@ -52,6 +52,8 @@ template <class T> Operand<T> opB(char t, const T* p, int ld) {
 struct Epi {
     int uplo = 0;       // 0 full, 1 write only i<=j, 2 write only i>=j
     int herm_diag = 0;  // force Im C(i,i) = 0
+    int inplace = 0;    // C aliases an operand: 1 = B operand (needs ONE tile along M, M <= 64),
+                        //                       2 = A operand (needs ONE tile along N, N <= 64)
 };
 
 // C(MxN) = alpha * A * B + beta * C.

@@ -252,12 +252,27 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g, int splits) {
 
 template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits) {
     if (g.M <= 0 || g.N <= 0) return;
+    // pick the largest tile that still yields about one workgroup per CU: a 64x64x64 complex
+    // tile is ~256 dependent MFMAs per wave (~15 us), so small problems want many small tiles.
+    long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * splits;
+    if (g.epi.inplace == 1) {  // all of M inside one workgroup; narrow tiles along N for parallelism
+        if ((long)((g.N + 63) / 64) >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
+        else launch_gemm<T, 64, 32>(st, g, splits);
+        return;
+    }
+    if (g.epi.inplace == 2) {
+        if ((long)((g.M + 63) / 64) >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
+        else launch_gemm<T, 32, 64>(st, g, splits);
+        return;
+    }
     if constexpr (Tr<T>::cx) {
-        launch_gemm<T, 64, 64>(st, g, splits);
+        if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
+        else launch_gemm<T, 32, 32>(st, g, splits);
     } else {
         long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
         if (tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
-        else launch_gemm<T, 64, 64>(st, g, splits);
+        else if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
+        else launch_gemm<T, 32, 32>(st, g, splits);
     }
 }
 
@@ -458,8 +473,9 @@ template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* 
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
     if (n <= DB) {
+        Epi e; e.inplace = 1;
         gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
-                Tr<T>::zero(), X, ldx);
+                Tr<T>::zero(), X, ldx, e);
         return;
     }
     int n1 = split_n1(n), n2 = n - n1;
@@ -473,8 +489,9 @@ template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* 
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
     if (n <= DB) {
+        Epi e; e.inplace = 1;
         gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
-                Tr<T>::zero(), X, ldx);
+                Tr<T>::zero(), X, ldx, e);
         return;
     }
     int n1 = split_n1(n), n2 = n - n1;
@@ -489,8 +506,9 @@ template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* 
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
     if (n <= DB) {
+        Epi e; e.inplace = 2;
         gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
-                Tr<T>::zero(), X, ldx);
+                Tr<T>::zero(), X, ldx, e);
         return;
     }
     int n1 = split_n1(n), n2 = n - n1;

@@ -24,9 +24,14 @@ template <class T> __global__ void __launch_bounds__(256) widen_kernel(int n, in
 // finish_T_block_kernel (zheevd_gpu.F90:215-279): Tm holds S = V^H V (lower) on entry.
 //   T(r,j) <- -tau(j) S(r,j) (r>j), T(j,j) <- tau(j), then for col = K-2..0:
 //   T(r,col) <- sum_{j=col+1..r} T(j,col) T(r,j), r > col.   Upper part is zeroed.
-template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int K, T* Tm, int ldt, const T* tau) {
+// Batched: workgroup b finishes the T factor of reflector block b (K = min(nb2, k - b*nb2)).
+template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, int nb2, T* Tall, int ldt, const T* tau_all) {
     __shared__ T t[64][65];  // t[col][row]
     const int tx = threadIdx.x;
+    const int i0 = blockIdx.x * nb2;
+    const int K = (k - i0 < nb2) ? k - i0 : nb2;
+    T* Tm = Tall + (size_t)blockIdx.x * ldt * ldt;
+    const T* tau = tau_all + i0;
     for (int j = 0; j < K; ++j) {
         T v = Tr<T>::zero();
         if (tx < K) {
@@ -73,8 +78,8 @@ static void back_transform(Ctx& c, hipStream_t st, int N, int m, const T* A, int
         Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
         Epi e; e.uplo = 2;
         gemm_splitk<T>(c, st, ib, ib, mi, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tb, ldt, 256, e);
-        hipLaunchKernelGGL((finish_T_kernel<T>), dim3(1), dim3(64), 0, st, ib, Tb, ldt, tau + i);
     }
+    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
     EIG_HIP(hipGetLastError());
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;

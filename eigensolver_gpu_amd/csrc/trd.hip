@@ -26,7 +26,7 @@
 namespace eig {
 
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
-constexpr int CH = 1024;   // rows per gemv partial chunk
+constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
 constexpr int NBMAX = 64;  // maximum panel width
 
 template <class T> struct PanelArgs {
@@ -86,113 +86,153 @@ template <class T> __device__ void larfg_scalars(double ss, T alpha, double& bet
 }
 
 // ------------------------------------------------------------------------------------------
-// panel_row_kernel
+// panel_row_kernel : 16 rows x 16 column-groups per workgroup.  Every global load the kernel
+// needs (gemv partials, v^H A v partials, the row-i data for w_i, this thread's slice of the V/W
+// panel and of the hemv partials) is issued before the first barrier, so the kernel costs one
+// memory round trip plus a handful of LDS reductions instead of a chain of dependent loads.
 // ------------------------------------------------------------------------------------------
+constexpr int RR = 16;   // rows per workgroup
+constexpr int RG = 16;   // column groups per workgroup
+constexpr int RU = 4;    // panel columns per group (NBMAX / RG)
+constexpr int RP = 8;    // hemv stripes per group (supports N <= RP*RG*HT = 8192; larger loops)
+
 template <class T>
 __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_finish, int do_update) {
     const int i = a.i, c = i + 1;
     const int npo = do_finish ? a.np - 1 - c : 0;  // columns older than c inside the panel
     const int wbase = a.np - a.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = blockIdx.x * 64 + lane;
+    const int rl = tid & (RR - 1), g = tid >> 4;
+    const int r = blockIdx.x * RR + rl;
     const int rows = i + 1;
     const bool active = r < rows;
-
-    __shared__ T z1s[NBMAX], z2s[NBMAX], rowW[NBMAX + 1], rowV[NBMAX + 1];
-    __shared__ T red2[4][64], red3[4][64];
-    __shared__ T sc_tau, sc_alpha, sc_S;
-    __shared__ double sc_zz;
-
     const int ntc = (c + HT - 1) / HT;  // hemv stripes of the column being finished (n = c)
 
+    __shared__ T z1s[NBMAX], z2s[NBMAX], rowW[NBMAX + 1], rowV[NBMAX + 1];
+    __shared__ T red2[RG][RR], red3[RG][RR];
+    __shared__ T s4[4];
+    __shared__ T sc_tau, sc_alpha;
+
+    // ---------------- phase 0: issue every load ----------------
+    T zs = Tr<T>::zero(), Ssum = Tr<T>::zero();
+    T wi_w = Tr<T>::zero(), wi_v = Tr<T>::zero(), wi_p = Tr<T>::zero();
+    T vv[RU], wv[RU], pp[RP];
+    T vr = Tr<T>::zero(), acur = Tr<T>::zero();
+#pragma unroll
+    for (int u = 0; u < RU; ++u) { vv[u] = Tr<T>::zero(); wv[u] = Tr<T>::zero(); }
+#pragma unroll
+    for (int u = 0; u < RP; ++u) pp[u] = Tr<T>::zero();
     if (do_finish) {
         if (tid < 2 * NBMAX) {
             int which = tid >> 6, kk = tid & 63;
-            if (kk < npo) {
-                T s = Tr<T>::zero();
-                for (int ch = 0; ch < a.nchunk; ++ch) s = s + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
-                if (which == 0) z1s[kk] = s; else z2s[kk] = s;
-            }
-        } else if (wave == 2) {
-            T s = Tr<T>::zero();
-            for (int g = lane; g < a.gh; g += 64) s = s + a.S[g];
-            s = wave_sum(s);
-            if (lane == 0) { sc_S = s; sc_tau = a.tau[c - 1]; }
+            if (kk < npo)
+                for (int ch = 0; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
         }
+        for (int q = tid; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
+        if (do_update && wave == 0) {
+            if (lane < npo) {
+                int k = c + 1 + lane;
+                wi_w = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
+                wi_v = a.A[(size_t)i + (size_t)k * a.lda];
+            }
+            for (int q = lane; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];
+        }
+        if (active) {
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                int kk = g + RG * u;
+                if (kk < npo) {
+                    int k = c + 1 + kk;
+                    vv[u] = a.A[(size_t)r + (size_t)k * a.lda];
+                    wv[u] = a.W[(size_t)r + (size_t)(k - wbase) * a.ldw];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RP; ++u) {
+                int q = g + RG * u;
+                if (q < ntc) pp[u] = a.P[(size_t)q * a.ldp + r];
+            }
+            for (int q = g + RG * RP; q < ntc; q += RG) pp[0] = pp[0] + a.P[(size_t)q * a.ldp + r];
+            if (g == 0) vr = a.A[(size_t)r + (size_t)c * a.lda];
+        }
+    }
+    if (do_update && active && g == 0) acur = a.A[(size_t)r + (size_t)i * a.lda];
+
+    if (do_finish) {
+        // ---------------- phase 1: gemv sums, v^H A v ----------------
+        if (tid < 2 * NBMAX) {
+            int which = tid >> 6, kk = tid & 63;
+            if (kk < npo) { if (which == 0) z1s[kk] = zs; else z2s[kk] = zs; }
+        }
+        Ssum = wave_sum(Ssum);
+        if (lane == 0) s4[wave] = Ssum;
+        if (tid == 0) sc_tau = a.tau[c - 1];
         __syncthreads();
+        // ---------------- phase 2: alpha, w_i ----------------
         if (wave == 0) {
             double zz = 0.0;
+            T u = wi_p;
             if (lane < npo) {
                 T t = Tr<T>::zero();
                 fmac_(t, z1s[lane], z2s[lane]);
                 zz = real_(t);
+                u = u - (wi_w * z1s[lane] + wi_v * z2s[lane]);
+                rowW[lane] = conj_(wi_w);
+                rowV[lane] = conj_(wi_v);
             }
             zz = wave_sum(zz);
+            if (do_update) u = wave_sum(u);
             if (lane == 0) {
                 T tau = sc_tau;
-                // alpha = -1/2 tau * (w'^H v),  w'^H v = conj(tau) * conj(S - 2 Re(z1^H z2))
-                T inner = conj_(sc_S - Tr<T>::make(2.0 * zz, 0.0));
-                sc_alpha = (-0.5 * abs2_(tau)) * inner;
-                sc_zz = zz;
-            }
-        }
-        __syncthreads();
-        if (do_update && wave == 0) {
-            // w_i : last row (row i) of the column being finished, needed by every row's update
-            T u = Tr<T>::zero();
-            for (int q = lane; q < ntc; q += 64) u = u + a.P[(size_t)q * a.ldp + i];
-            if (lane < npo) {
-                int k = c + 1 + lane;
-                T wv = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
-                T vv = a.A[(size_t)i + (size_t)k * a.lda];
-                T t = wv * z1s[lane] + vv * z2s[lane];
-                u = u - t;
-                rowW[lane] = conj_(wv);
-                rowV[lane] = conj_(vv);
-            }
-            u = wave_sum(u);
-            if (lane == 0) {
-                T vic = a.A[(size_t)i + (size_t)c * a.lda];
-                T wi = sc_tau * u + sc_alpha * vic;
-                rowW[npo] = conj_(wi);
-                rowV[npo] = conj_(vic);
+                T S = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                // alpha = -1/2 tau (w'^H v),  w'^H v = conj(tau) conj(S - 2 Re(z1^H z2))
+                T alpha = (-0.5 * abs2_(tau)) * conj_(S - Tr<T>::make(2.0 * zz, 0.0));
+                sc_alpha = alpha;
+                if (do_update) {
+                    T vic = a.A[(size_t)i + (size_t)c * a.lda];
+                    T wi = tau * u + alpha * vic;
+                    rowW[npo] = conj_(wi);
+                    rowV[npo] = conj_(vic);
+                }
             }
         }
         __syncthreads();
     }
 
+    // ---------------- phase 3: this thread's slice ----------------
     T acc2 = Tr<T>::zero(), acc3 = Tr<T>::zero();
     if (do_finish && active) {
-        for (int kk = wave; kk < npo; kk += 4) {
-            int k = c + 1 + kk;
-            T vv = a.A[(size_t)r + (size_t)k * a.lda];
-            T wv = a.W[(size_t)r + (size_t)(k - wbase) * a.ldw];
-            acc2 = acc2 - (wv * z1s[kk] + vv * z2s[kk]);
-            if (do_update) acc3 = acc3 + (vv * rowW[kk] + wv * rowV[kk]);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            int kk = g + RG * u;
+            if (kk < npo) {
+                acc2 = acc2 - (wv[u] * z1s[kk] + vv[u] * z2s[kk]);
+                if (do_update) acc3 = acc3 + (vv[u] * rowW[kk] + wv[u] * rowV[kk]);
+            }
         }
-        for (int q = wave; q < ntc; q += 4) acc2 = acc2 + a.P[(size_t)q * a.ldp + r];
+#pragma unroll
+        for (int u = 0; u < RP; ++u) acc2 = acc2 + pp[u];
     }
-    red2[wave][lane] = acc2;
-    red3[wave][lane] = acc3;
+    red2[g][rl] = acc2;
+    red3[g][rl] = acc3;
     __syncthreads();
-    if (wave == 0) {
+    // ---------------- phase 4: one thread per row finishes ----------------
+    if (tid < RR) {
         double contrib = 0.0;
         if (active) {
-            T anew = Tr<T>::zero();
+            T anew = acur;
             if (do_finish) {
-                T u = (red2[0][lane] + red2[1][lane]) + (red2[2][lane] + red2[3][lane]);
-                T vr = a.A[(size_t)r + (size_t)c * a.lda];
+                T u = Tr<T>::zero(), upd = Tr<T>::zero();
+#pragma unroll
+                for (int q = 0; q < RG; ++q) { u = u + red2[q][rl]; upd = upd + red3[q][rl]; }
                 T wr = sc_tau * u + sc_alpha * vr;
                 a.W[(size_t)r + (size_t)(c - wbase) * a.ldw] = wr;
                 if (do_update) {
-                    T upd = (red3[0][lane] + red3[1][lane]) + (red3[2][lane] + red3[3][lane]);
                     upd = upd + (vr * rowW[npo] + wr * rowV[npo]);
-                    anew = a.A[(size_t)r + (size_t)i * a.lda] - upd;
+                    anew = acur - upd;
                     if (r == i) anew = Tr<T>::realpart(anew);
                     a.A[(size_t)r + (size_t)i * a.lda] = anew;
                 }
-            } else if (do_update) {
-                anew = a.A[(size_t)r + (size_t)i * a.lda];
             }
             if (do_update) {
                 a.xbuf[r] = anew;
@@ -201,8 +241,9 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
             }
         }
         if (do_update) {
-            contrib = wave_sum(contrib);
-            if (lane == 0) a.NP[blockIdx.x] = contrib;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+            if (tid == 0) a.NP[blockIdx.x] = contrib;
         }
     }
 }
@@ -211,6 +252,8 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
 // panel_mv_kernel : larfg scalars + Hermitian mat-vec (upper, each element read once) + stacked
 // conjugate-transposed panel products.  Also used stand-alone (bench / zhemv entry point) with
 // `plain` != 0: v = xbuf as is, no scalars, no gemv part.
+// Grid = [gemv workgroups | hemv workgroups]: the (short, latency-bound) gemv items start first
+// and hide under the bandwidth-bound tiles.  Loads are issued before the scalar prologue.
 // ------------------------------------------------------------------------------------------
 template <class T, int NCOL>
 __device__ __forceinline__ void transpose_reduce16(T (&t)[NCOL], int lane, T& out) {
@@ -250,18 +293,86 @@ __device__ __forceinline__ void transpose_reduce16(T (&t)[NCOL], int lane, T& ou
     out = out + shx(out, 1);
 }
 
+__device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
+    // t = J(J+1)/2 + I, I <= J
+    J = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((J + 1) * (J + 2) / 2 <= t) ++J;
+    while (J * (J + 1) / 2 > t) --J;
+    I = t - J * (J + 1) / 2;
+}
+
 template <class T>
-__global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain) {
+__global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain, int gg) {
     const int i = a.i, n = i;  // v has n entries (rows 0..i-1), v(n-1) = 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     __shared__ T redy[4][64];
     __shared__ T redt[64];
     __shared__ T sc_scale;
+    const bool is_gemv = (int)blockIdx.x < gg;
+    const int hb = (int)blockIdx.x - gg;  // hemv workgroup index
 
+    // raw (unscaled) entry of the column; the scale is applied after the prologue
+    auto xraw = [&](int r) -> T { return (r < n) ? a.xbuf[r] : Tr<T>::zero(); };
+    auto vfix = [&](T x, int r, T scale) -> T {
+        if (plain) return x;
+        if (r < n - 1) return scale * x;
+        return (r == n - 1) ? Tr<T>::one() : Tr<T>::zero();
+    };
+
+    // ---------------- issue the first batch of loads ----------------
+    const int nt = (n + HT - 1) / HT;
+    const int ntiles = nt * (nt + 1) / 2;
+    __shared__ T xcs[2][HT];   // raw column entries of v for the current / next tile
+    T av[16];
+    T xr = Tr<T>::zero();
+    int I = 0, J = 0, t = hb, buf = 0;
+    // gemv item
+    int g_which = 0, g_kk = 0, g_rbeg = 0, g_rend = 0, g_ch = 0;
+    bool g_ok = false;
+    const int wbase = a.np - a.nb;
+    auto load_tile = [&](int b) {
+        tile_decode(t, I, J);
+        const int r0 = I * HT, c0 = J * HT, r = r0 + lane;
+        const bool diag = (I == J);
+        xr = xraw(r);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int cc = c0 + wave * 16 + j;
+            bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
+            T v = Tr<T>::zero();
+            if (ok) v = a.A[(size_t)r + (size_t)cc * a.lda];
+            if (diag && r == cc) v = Tr<T>::realpart(v);
+            av[j] = v;
+        }
+        if (tid < HT) xcs[b][tid] = xraw(c0 + tid);
+    };
+    if (is_gemv) {
+        const int npo = a.np - 1 - i;
+        const int item = (int)blockIdx.x * 4 + wave;
+        g_ok = item < 2 * npo * a.nchunk;
+        if (g_ok) {
+            g_ch = item / (2 * npo);
+            int rem = item % (2 * npo);
+            g_which = rem / npo; g_kk = rem % npo;
+            int k = i + 1 + g_kk;
+            const T* src = g_which == 0 ? a.A + (size_t)k * a.lda : a.W + (size_t)(k - wbase) * a.ldw;
+            g_rbeg = g_ch * CH; g_rend = min(n, g_rbeg + CH);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int r = g_rbeg + lane + 64 * j;
+                av[j] = (r < g_rend) ? src[r] : Tr<T>::zero();
+                av[8 + j] = (r < g_rend) ? a.xbuf[r] : Tr<T>::zero();
+            }
+        }
+    } else if (t < ntiles) {
+        load_tile(0);
+    }
+
+    // ---------------- scalar prologue (every workgroup, deterministic) ----------------
     if (!plain) {
         if (wave == 0) {
             double ss = 0.0;
-            for (int g = lane; g < a.nblkA; g += 64) ss += a.NP[g];
+            for (int q = lane; q < a.nblkA; q += 64) ss += a.NP[q];
             ss = wave_sum(ss);
             if (lane == 0) {
                 double beta;
@@ -274,93 +385,74 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
                 }
             }
         }
+    }
+    __syncthreads();
+    const T scale = plain ? Tr<T>::one() : sc_scale;
+
+    if (is_gemv) {
+        // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk)
+        if (g_ok) {
+            T s = Tr<T>::zero();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int r = g_rbeg + lane + 64 * j;
+                fmac_(s, av[j], vfix(av[8 + j], r, scale));
+            }
+            s = wave_sum(s);
+            if (lane == 0) a.Zp[(size_t)(g_ch * 2 + g_which) * NBMAX + g_kk] = s;
+        }
+        return;
+    }
+
+    T Sacc = Tr<T>::zero();
+    while (t < ntiles) {
+        const int r0 = I * HT, c0 = J * HT;
+        const bool diag = (I == J);
+        const int r = r0 + lane;
+        const T vr = vfix(xr, r, scale);
+        T yI = Tr<T>::zero();
+        T tj[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int cc = c0 + wave * 16 + j;
+            T vc = vfix(xcs[buf][wave * 16 + j], cc, scale);
+            fma_(yI, av[j], vc);
+            T p = Tr<T>::zero();
+            if (!(diag && r == cc)) fmac_(p, av[j], vr);
+            tj[j] = p;
+        }
+        T tval;
+        transpose_reduce16<T, 16>(tj, lane, tval);
+        redy[wave][lane] = yI;
+        if ((lane & 3) == 0) redt[wave * 16 + (lane >> 2)] = tval;
+        // own row/column entries of v for the S partial (tid < 64)
+        T vI = Tr<T>::zero(), vJ = Tr<T>::zero();
+        if (tid < 64) { vI = vfix(xraw(r0 + tid), r0 + tid, scale); vJ = vfix(xcs[buf][tid], c0 + tid, scale); }
+        const int Ic = I, Jc = J;
+        t += a.gh;
+        if (t < ntiles) load_tile(buf ^ 1);   // next tile's loads fly while the barriers drain
+        __syncthreads();
+        if (tid < 64) {
+            T yv = (redy[0][tid] + redy[1][tid]) + (redy[2][tid] + redy[3][tid]);
+            T tv = redt[tid];
+            if (diag) {
+                T s = yv + tv;
+                a.P[(size_t)Jc * a.ldp + r0 + tid] = s;
+                fmac_(Sacc, vI, s);
+                if (!plain && c0 + tid < n) a.A[(size_t)(c0 + tid) + (size_t)i * a.lda] = vJ;
+            } else {
+                a.P[(size_t)Jc * a.ldp + r0 + tid] = yv;
+                a.P[(size_t)Ic * a.ldp + c0 + tid] = tv;
+                fmac_(Sacc, vI, yv);
+                fmac_(Sacc, vJ, tv);
+            }
+        }
+        buf ^= 1;
         __syncthreads();
     }
-    const T scale = plain ? Tr<T>::one() : sc_scale;
-    auto vget = [&](int r) -> T {
-        if (plain) return (r < n) ? a.xbuf[r] : Tr<T>::zero();
-        if (r < n - 1) return scale * a.xbuf[r];
-        return (r == n - 1) ? Tr<T>::one() : Tr<T>::zero();
-    };
-
-    if ((int)blockIdx.x < a.gh) {
-        const int nt = (n + HT - 1) / HT;
-        const int ntiles = nt * (nt + 1) / 2;
-        T Sacc = Tr<T>::zero();
-        for (int t = blockIdx.x; t < ntiles; t += a.gh) {
-            // t = J(J+1)/2 + I, I <= J
-            int J = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((J + 1) * (J + 2) / 2 <= t) ++J;
-            while (J * (J + 1) / 2 > t) --J;
-            const int I = t - J * (J + 1) / 2;
-            const int r0 = I * HT, c0 = J * HT;
-            const bool diag = (I == J);
-            const int r = r0 + lane;
-            const T vr = vget(r);
-            T av[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int cc = c0 + wave * 16 + j;
-                bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
-                T v = Tr<T>::zero();
-                if (ok) v = a.A[(size_t)r + (size_t)cc * a.lda];
-                if (diag && r == cc) v = Tr<T>::realpart(v);
-                av[j] = v;
-            }
-            T yI = Tr<T>::zero();
-            T tj[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int cc = c0 + wave * 16 + j;
-                T vc = vget(cc);
-                fma_(yI, av[j], vc);
-                T p = Tr<T>::zero();
-                if (!(diag && r == cc)) fmac_(p, av[j], vr);
-                tj[j] = p;
-            }
-            T tval;
-            transpose_reduce16<T, 16>(tj, lane, tval);
-            redy[wave][lane] = yI;
-            if ((lane & 3) == 0) redt[wave * 16 + (lane >> 2)] = tval;
-            __syncthreads();
-            if (tid < 64) {
-                T yv = (redy[0][tid] + redy[1][tid]) + (redy[2][tid] + redy[3][tid]);
-                T tv = redt[tid];
-                T vI = vget(r0 + tid), vJ = vget(c0 + tid);
-                if (diag) {
-                    T s = yv + tv;
-                    a.P[(size_t)J * a.ldp + r0 + tid] = s;
-                    fmac_(Sacc, vI, s);
-                    if (!plain && c0 + tid < n) a.A[(size_t)(c0 + tid) + (size_t)i * a.lda] = vJ;
-                } else {
-                    a.P[(size_t)J * a.ldp + r0 + tid] = yv;
-                    a.P[(size_t)I * a.ldp + c0 + tid] = tv;
-                    fmac_(Sacc, vI, yv);
-                    fmac_(Sacc, vJ, tv);
-                }
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-            Sacc = wave_sum(Sacc);
-            if (lane == 0) a.S[blockIdx.x] = Sacc;
-        }
-    } else {
-        // stacked conjugate-transposed products  z1 = V^H v, z2 = W^H v  (partials per row chunk)
-        const int npo = a.np - 1 - i;
-        const int wbase = a.np - a.nb;
-        const int item = ((int)blockIdx.x - a.gh) * 4 + wave;
-        if (item < 2 * npo * a.nchunk) {
-            int ch = item / (2 * npo), rem = item % (2 * npo);
-            int which = rem / npo, kk = rem % npo;
-            int k = i + 1 + kk;
-            const T* src = which == 0 ? a.A + (size_t)k * a.lda : a.W + (size_t)(k - wbase) * a.ldw;
-            int rbeg = ch * CH, rend = min(n, rbeg + CH);
-            T s = Tr<T>::zero();
-            for (int r = rbeg + lane; r < rend; r += 64) fmac_(s, src[r], vget(r));
-            s = wave_sum(s);
-            if (lane == 0) a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk] = s;
-        }
+    if (wave == 0) {
+        Sacc = wave_sum(Sacc);
+        if (lane == 0) a.S[hb] = Sacc;
     }
 }
 
@@ -486,7 +578,7 @@ template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N) {
     s.S = c.scratch<T>("trd_S", 8192);
     int nchunk = (N + CH - 1) / CH;
     s.Zp = c.scratch<T>("trd_Zp", (size_t)(nchunk + 1) * 2 * NBMAX);
-    s.NP = c.scratch<double>("trd_NP", (size_t)nt + 64);
+    s.NP = c.scratch<double>("trd_NP", (size_t)(N / RR) + 64);
     s.alphaSlot = c.scratch<T>("trd_alpha", 8);
     return s;
 }
@@ -503,7 +595,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         const int do_finish = (i < np - 1), do_update = !last;
         a.i = i;
         a.gh = gh_prev; a.nchunk = nchunk_prev;
-        int gA = (i + 1 + 63) / 64;
+        int gA = (i + 1 + RR - 1) / RR;
         if (!mv_only) hipLaunchKernelGGL((panel_row_kernel<T>), dim3(gA), dim3(256), 0, st, a, do_finish, do_update);
         if (last) break;
         // mat-vec for column i (v has i entries)
@@ -513,7 +605,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         int npo = np - 1 - i;
         int gg = (2 * npo * nchunk + 3) / 4;
         a.nblkA = gA; a.gh = gh; a.nchunk = nchunk;
-        hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(256), 0, st, a, 0);
+        hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(256), 0, st, a, 0, gg);
         if (nlaunch) ++*nlaunch;
         if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
         gh_prev = gh; nchunk_prev = nchunk;
@@ -554,7 +646,7 @@ template <class T>
 void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes) {
     if (nb <= 0 || nb > NBMAX) nb = NBMAX;
     TrdScratch<T> sc = trd_scratch<T>(c, N);
-    std::vector<double> ones((size_t)((N + HT - 1) / HT) + 64, 1.0);
+    std::vector<double> ones((size_t)(N / RR) + 64, 1.0);
     EIG_HIP(hipMemcpyAsync(sc.NP, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, st));
     T one = Tr<T>::one();
     EIG_HIP(hipMemcpyAsync(sc.alphaSlot, &one, sizeof(T), hipMemcpyHostToDevice, st));
@@ -579,7 +671,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
     a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
     a.gh = hemv_grid(c, n);
-    hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(256), 0, st, a, 1);
+    hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(256), 0, st, a, 1, 0);
     if (gather) {
         int nt = (n + HT - 1) / HT;
         hipLaunchKernelGGL((hemv_gather_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, n, nt, (const T*)sc.P, sc.ldp, y);

@@ -371,3 +371,18 @@ def test_full_size_properties(env, cfg):
     assert abs(w.sum() - tr) <= 1e-9 * abs(tr)
     wl = sl.eigh(A, B, eigvals_only=True, subset_by_index=[0, m - 1], driver="gvx")
     assert oracle.compare_1d(wl, w[:m])[0] <= 1e-12
+
+
+def test_fortran_dropin_driver(env):
+    """The Fortran modules zhegvdx_gpu / eigsolve_vars / nvtx_inters (same names and argument order as
+    the reference) called from a Fortran program built with amdflang, like test_driver/test_zhegvdx.F90."""
+    import subprocess
+    torch, oracle, api = env
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eigensolver_gpu_amd", "fortran",
+                       "test_zhegvdx")
+    if not os.path.exists(exe):
+        pytest.skip("Fortran driver not built (amdflang missing at build time)")
+    envv = dict(os.environ, EIGSOLVE_LAPACK_LIB=api.find_host_lapack() or "")
+    out = subprocess.run([exe, "300", "75"], capture_output=True, text=True, env=envv, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASSED" in out.stdout
