@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=0, help="order of the CPU baseline sample (default: min(n, 2048))")
+    ap.add_argument("--tridiag", choices=["device", "host"], default="device",
+                    help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,6 +98,7 @@ def main():
     # each rank's host dstedc gets an equal share of the host cores
     api.lib()
     api.set_host_threads(max(1, min(64, cores // max(world, 1))))
+    api.set_option("tridiag", 1 if args.tridiag == "device" else 0)
 
     # ---- stage W+K pristine input pairs in HBM ------------------------------------------------
     A0, B0 = gen_pair(n, cplx, 1000 + rank, dev)
@@ -171,6 +174,7 @@ def main():
             "phase_ms_median": ph,
             "residual": resid, "residual_bound_N_eps": n * 2.220446049250313e-16, "b_orthonormality": bortho,
             "host_cores": cores,
+            "tridiagonal_solver": "device divide&conquer (stedc.hip)" if args.tridiag == "device" else "host LAPACK dstedc (reference behaviour)",
         }
 
     # ---- roofline legs (rank 0, N=1 semantics: run on this rank's GPU after the timed region) --------

@@ -37,6 +37,7 @@ EXPORTS = [
     "eigsolve_dsymv_bench", "eigsolve_zgemm", "eigsolve_dgemm", "eigsolve_zgemm_bench", "eigsolve_dgemm_bench",
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
     "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
+    "eigsolve_dstedc_device",
 ]
 
 
@@ -348,3 +349,17 @@ def hetrd_mv_sweep(A_d, nb=0, reps=1):
                               ctypes.byref(nl), ctypes.byref(by))
     assert rc == 0
     return {"ms_total": ms.value, "launches": nl.value, "algo_bytes": by.value}
+
+
+def stedc_device(d, e):
+    """Device divide & conquer on a symmetric tridiagonal (numpy d[N], e[N-1]) -> (w, Q, ms)."""
+    import torch
+    _sync()
+    N = len(d)
+    dd = torch.from_numpy(np.ascontiguousarray(d, dtype=np.float64)).cuda()
+    ed = torch.from_numpy(np.ascontiguousarray(np.r_[e, 0.0], dtype=np.float64)).cuda()
+    w = torch.zeros(N, dtype=torch.float64, device="cuda")
+    Q = torch.zeros((N, N), dtype=torch.float64, device="cuda")
+    ms = ctypes.c_double(0)
+    rc = lib().eigsolve_dstedc_device(c_int(N), _p(dd), _p(ed), _p(w), _p(Q), c_int(N), ctypes.byref(ms))
+    return rc, w.cpu().numpy(), to_host(Q), ms.value

@@ -88,6 +88,11 @@ using stedc_fn = void (*)(const char*, const int*, double*, double*, double*, co
 
 enum Phase { PH_POTRF = 0, PH_GST, PH_TRD, PH_STEDC, PH_BT, PH_TRSM, PH_D2H, PH_TOTAL, PH_COUNT };
 
+// Default for the tridiagonal step: 1 = device divide & conquer (~100x faster than
+// the host dstedc at N=4096); EIGSOLVE_TRIDIAG=host / eigsolve_set_option("tridiag", 0) restores the
+// reference behaviour (host LAPACK).
+constexpr int kTridiagDefault = 1;
+
 struct Ctx {
     int dev = -1;
     hipStream_t s1 = nullptr;  // compute stream
@@ -104,6 +109,7 @@ struct Ctx {
     int trd_nb = 64;
     int bt_nb = 64;
     int hemv_blocks = 0;  // 0 = auto
+    int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
 
     template <class T> T* scratch(const char* name, size_t count) {
         return reinterpret_cast<T*>(scratch_bytes(name, count * sizeof(T)));

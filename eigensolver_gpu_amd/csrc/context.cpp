@@ -103,6 +103,7 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c->trd_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
     if (c->bt_nb < 1 || c->bt_nb > 64) c->bt_nb = 64;
     t_ctx[dev] = c;
@@ -217,6 +218,7 @@ int eigsolve_set_option(const char* name, int value) {
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
+        else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;
     } catch (...) {

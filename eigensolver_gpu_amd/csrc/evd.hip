@@ -7,6 +7,7 @@
 #include <functional>
 
 #include "../../include/eigsolve_gpu.h"
+#include "stedc.h"
 #include "trd.h"
 
 namespace eig {
@@ -134,6 +135,24 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     pt.begin(PH_TRD);
     hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
     pt.end(PH_TRD);
+    if (c.tridiag_device) {
+        // device-side divide & conquer: no N x N host round trip at all
+        EIG_HIP(hipStreamSynchronize(st));
+        pt.collect(PH_TRD);
+        double t0 = now_ms();
+        double* Qd = nullptr;
+        int ldq_d = 0;
+        if (stedc_device(c, st, N, w_d, e_d, w_d, &Qd, &ldq_d) != 0) {
+            printf(" eigsolve error: device tridiagonal eigensolver failed!\n");
+            return -1;
+        }
+        size_t tot = (size_t)N * m;
+        hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m,
+                           (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Z, ldz);
+        EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        EIG_HIP(hipStreamSynchronize(st));
+        c.phase_ms[PH_STEDC] += now_ms() - t0;
+    } else {
     // d, e -> host (zheevd_gpu.F90:85-86)
     EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     if (N > 1) EIG_HIP(hipMemcpyAsync(e_h, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
@@ -162,6 +181,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
                        ldz);
     EIG_HIP(hipStreamSynchronize(st));
     c.phase_ms[PH_STEDC] += now_ms() - t0;
+    }
     pt.begin(PH_BT);
     back_transform<T>(c, st, N, m, A, lda, tau_d, Z, ldz, c.bt_nb);
     pt.end(PH_BT);
@@ -531,4 +551,20 @@ int eigsolve_zhetrd_mv_sweep(int N, void* A_d, int lda, int nb, int reps, double
 }
 int eigsolve_dsytrd_mv_sweep(int N, double* A_d, int lda, int nb, int reps, double* ms_total, long* nlaunch, double* algo_bytes) {
     return mv_sweep_entry<double>(N, A_d, lda, nb, reps, ms_total, nlaunch, algo_bytes);
+}
+
+// Device divide & conquer on (d,e): w_d[N] ascending, Q_d (N x N, ld ldq) eigenvectors.  Test / bench entry point.
+int eigsolve_dstedc_device(int N, const double* d_d, const double* e_d, double* w_d, double* Q_d, int ldq, double* ms) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        double t0 = now_ms();
+        double* Qs = nullptr;
+        int lds_ = 0;
+        int r = stedc_device(c, c.s1, N, d_d, e_d, w_d, &Qs, &lds_);
+        if (r == 0 && Q_d)
+            EIG_HIP(hipMemcpy2DAsync(Q_d, sizeof(double) * ldq, Qs, sizeof(double) * lds_, sizeof(double) * N, N, hipMemcpyDeviceToDevice, c.s1));
+        EIG_HIP(hipStreamSynchronize(c.s1));
+        if (ms) *ms = now_ms() - t0;
+        return r;
+    });
 }

@@ -39,8 +39,9 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks"};
- * value<=0 restores the CDNA4 default.  Returns 0 / -1 (unknown name). */
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag"};
+ * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
+ * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 
 /* nvtxStartRange / nvtxEndRange (lib_eigsolve/toolbox.F90:71-97) -> roctx ranges when
@@ -158,6 +159,11 @@ int eigsolve_dsyr2k_bench(int n, int k, const double *V_d, int ldv, const double
  * as left in B_d by ?potrf above (its inverted diagonal blocks are rebuilt here). */
 int eigsolve_ztrsm_lun(int N, int m, const void *U_d, int ldu, void *Z_d, int ldz);
 int eigsolve_dtrsm_lun(int N, int m, const double *U_d, int ldu, double *Z_d, int ldz);
+
+/* Device-side divide & conquer for the symmetric tridiagonal (d_d[N], e_d[N-1]) -- the "next" row
+ * replacing the host zstedc/dstedc('I') of zheevd_gpu.F90:101.  w_d[N] ascending, Q_d (N x N, ldq)
+ * eigenvectors (may be NULL), *ms host wall time.  d_d/e_d are not modified (w_d may alias d_d). */
+int eigsolve_dstedc_device(int N, const double *d_d, const double *e_d, double *w_d, double *Q_d, int ldq, double *ms);
 
 /* Library version / build info string. */
 const char *eigsolve_version(void);

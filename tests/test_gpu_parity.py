@@ -386,3 +386,71 @@ def test_fortran_dropin_driver(env):
     out = subprocess.run([exe, "300", "75"], capture_output=True, text=True, env=envv, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASSED" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------
+# device-side divide & conquer replacing the host zstedc/dstedc
+# ---------------------------------------------------------------------------------------------
+def _tridiag_cases():
+    rng = np.random.default_rng(0)
+    cases = []
+    for n in (1, 2, 5, 31, 32, 33, 64, 65, 100, 257, 1000):
+        cases.append(("random%d" % n, rng.standard_normal(n), rng.standard_normal(max(n - 1, 0))))
+    n = 600
+    cases.append(("laplacian", np.ones(n) * 2, -np.ones(n - 1)))
+    cases.append(("wilkinson", np.abs(np.arange(n) - n // 2).astype(float), np.ones(n - 1)))
+    dg = np.concatenate([np.abs(np.arange(21) - 10).astype(float)] * 20)
+    eg = np.ones(len(dg) - 1)
+    eg[20::21] = 1e-8
+    cases.append(("glued_wilkinson", dg, eg))
+    cases.append(("clustered", np.ones(n), 1e-9 * rng.standard_normal(n - 1)))
+    e0 = rng.standard_normal(n - 1)
+    e0[::7] = 0.0
+    cases.append(("zeros_in_e", rng.standard_normal(n), e0))
+    cases.append(("graded", 10.0 ** (-np.arange(n) / 30.0), 10.0 ** (-np.arange(n - 1) / 30.0) * 0.5))
+    cases.append(("huge", rng.standard_normal(n) * 1e150, rng.standard_normal(n - 1) * 1e150))
+    cases.append(("tiny", rng.standard_normal(n) * 1e-150, rng.standard_normal(n - 1) * 1e-150))
+    cases.append(("zero", np.zeros(n), np.zeros(n - 1)))
+    cases.append(("random2048", rng.standard_normal(2048) * 50 + 100, rng.standard_normal(2047) * 30))
+    return cases
+
+
+@pytest.mark.parametrize("case", _tridiag_cases(), ids=lambda c: c[0])
+def test_stedc_device_vs_lapack(env, case):
+    """Eigenvalues vs LAPACK, orthogonality and residual of the device divide & conquer on the matrix
+    families that stress deflation and the secular solver."""
+    torch, oracle, api = env
+    from scipy.linalg import eigh_tridiagonal
+    name, d, e = case
+    n = len(d)
+    rc, w, Q, ms = api.stedc_device(d, e)
+    assert rc == 0
+    wr = eigh_tridiagonal(d, e, eigvals_only=True) if n > 1 else d.copy()
+    nrm = max(np.abs(wr).max(), 1e-300)
+    assert np.all(np.diff(w) >= 0)
+    assert np.abs(w - wr).max() / nrm <= 50 * max(n, 8) * EPS / 8
+    assert np.abs(Q.T @ Q - np.eye(n)).max() <= 20 * max(n, 8) * EPS / 8 + 1e-14
+    T = np.diag(d) + (np.diag(e, 1) + np.diag(e, -1) if n > 1 else 0)
+    assert np.abs(T @ Q - Q * w).max() / nrm <= 20 * max(n, 8) * EPS / 8 + 1e-14
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,il,iu", [(1, 1, 1), (40, 1, 40), (257, 1, 64), (130, 5, 12), (700, 1, 175)])
+def test_hegvdx_device_tridiag_matches_host_path(env, cplx, n, il, iu):
+    """Same driver call with the tridiagonal step on the device vs on the host (reference behaviour)."""
+    torch, oracle, api = env
+    A = oracle.gen_spd_fast(n, 1000 + n, cplx)
+    B = oracle.gen_spd_fast(n, 2000 + n, cplx, shift=float(n))
+    res = {}
+    try:
+        for mode in (0, 1):
+            assert api.set_option("tridiag", mode) == 0
+            info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), il, iu)
+            assert info == 0
+            res[mode] = (w, Z)
+            assert oracle.residual(A, B, w[il - 1:iu], Z) <= max(n, 4) * EPS
+            assert oracle.b_orthonormality(B, Z) <= 1e-11
+    finally:
+        api.set_option("tridiag", -1)
+    assert oracle.compare_1d(res[0][0], res[1][0])[0] <= 1e-13
+    assert oracle.compare_abs2d(res[0][1], res[1][1])[0] <= 1e-8
