@@ -77,9 +77,14 @@ __device__ __forceinline__ void trim_k(const Operand<T>& o, int i0, int bsz, int
     }
 }
 
-constexpr int BK = 16;
+constexpr int BKL = 16;  // K-slab of the large tiles (register-prefetch pipelined)
+constexpr int BKS = 64;  // K-slab of the small tiles: K <= 64 (trsm/larfb/panel-sized products) is ONE stage
 
-template <class T, int BM, int BN, int TA, int TB>
+#ifndef EIG_MFMA444
+#define EIG_MFMA444 1
+#endif
+
+template <class T, int BM, int BN, int TA, int TB, int BK>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
     constexpr bool CX = Tr<T>::cx;
     constexpr int NPL = CX ? 2 : 1;
@@ -163,6 +168,47 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
         if (k0 + BK < kend) gload(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
+#if EIG_MFMA444
+            // v_mfma_f64_4x4x4_4b_f64 sustains ~72 TFLOP/s on gfx950 where 16x16x4 saturates at ~48
+            // (profiles/r01_microbench3_mfma_variants.txt).  Four of them, fed with the 4-row slices
+            // r = 0..3 of the B fragment (replicated over lane bits 2-3) against the unchanged 16-wide
+            // A fragment, produce exactly one 16x16x4 product; result r lands in component r of the
+            // accumulator: lane l holds C(m = l&15, n = 4r + (l>>4))
+            // (layout measured in profiles/r01_probe_mfma_f64_4x4x4_layout.txt).  blgp bit 0 negates.
+            double ar[TM], ai[TM], br[TN][4], bi[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                int m = wm0 + a * 16 + fi, k = kk + fk;
+                int off = TA == 0 ? k * LDA + m : m * LDA + k;
+                ar[a] = As[off];
+                if (CX) ai[a] = As[ASZ + off];
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = wn0 + b * 16 + 4 * r + (lane & 3), k = kk + fk;
+                    int off = TB == 0 ? k * LDB + n : n * LDB + k;
+                    br[b][r] = Bs[off];
+                    if (CX) bi[b][r] = Bs[BSZ + off];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ar[a], acc[0][a][b][r], 0, 0, 0);
+                        if (CX) {
+                            acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ai[a], acc[0][a][b][r], 0, 0, 1);
+                            acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ar[a], acc[NPL - 1][a][b][r], 0, 0, 0);
+                            acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ai[a], acc[NPL - 1][a][b][r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#else
             double ar[TM], ai[TM], br[TN], bi[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
@@ -191,6 +237,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
                     }
                 }
             }
+#endif
         }
     }
 
@@ -240,13 +287,14 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
 
 template <class T, int BM, int BN>
 static void launch_gemm(hipStream_t st, const GemmArgs<T>& g, int splits) {
+    constexpr int BK = (BM * BN <= 64 * 32) ? BKS : BKL;
     dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
     dim3 block(256);
     int ta = g.A.trans, tb = g.B.trans;
-    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 0>), grid, block, 0, st, g);
-    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 1>), grid, block, 0, st, g);
-    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 0>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 1>), grid, block, 0, st, g);
+    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 0, BK>), grid, block, 0, st, g);
+    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 1, BK>), grid, block, 0, st, g);
+    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 0, BK>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 1, BK>), grid, block, 0, st, g);
     EIG_HIP(hipGetLastError());
 }
 
@@ -289,7 +337,7 @@ template <class T>
 void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
                  T* C, int ldc, int kchunk, Epi epi) {
     if (M <= 0 || N <= 0) return;
-    kchunk = ((kchunk + BK - 1) / BK) * BK;
+    kchunk = ((kchunk + BKS - 1) / BKS) * BKS;
     int splits = (K + kchunk - 1) / kchunk;
     if (splits <= 1) {
         gemm(c, st, M, N, K, alpha, A, Bt, beta, C, ldc, epi);
@@ -322,88 +370,137 @@ template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* 
 constexpr int DB = kDiagBlk;
 constexpr int DBL = DB + 1;  // LDS leading dimension
 
-// In-LDS upper Cholesky (optional) followed by in-place inversion of the upper factor.
-//   do_chol = 1: a <- chol(a) (upper), written back to Ublk; info <- first bad pivot (1-based, global)
-//   inv block written to invblk (DB x DB, ld DB, identity-padded, zero below the diagonal).
+// 64x64 upper Cholesky (optional) followed by the inverse of the factor, one workgroup.
+// Register-resident: thread (tr, tc) = (tid/16, tid%16) owns the 4x4 block rows 4tr.., cols 4tc..
+// of U (and of X = U^-1).  Each of the 64 elimination steps broadcasts one row (and for the inverse
+// one column) through a double-buffered LDS line and costs a single barrier; every thread redoes the
+// scalar sqrt/reciprocal itself.  (~20 us instead of ~200 us for the LDS-resident column version;
+// this kernel sits on the critical path of potrf N/64 times.)
+//   do_chol = 1: block <- chol(block) (upper), written back; info <- first bad pivot (1-based, global)
+//   inverse written to invU (DB x DB, ld DB, identity-padded, zero below the diagonal).
 template <class T>
 __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, int ldu, T* invU, int do_chol, int k0_single,
                                                          int* info) {
-    __shared__ T a[DB * DBL];
-    __shared__ T colv[DB];
-    __shared__ double piv;
+    __shared__ T rowb[2][DB];
+    __shared__ T colb[2][DB];
     const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
     const int blk = (k0_single >= 0) ? k0_single / DB : blockIdx.x;
     const int k0 = blk * DB;
     const int nb = min(DB, n_total - k0);
     T* Ublk = Umat + (size_t)k0 + (size_t)k0 * ldu;
     T* inv = invU + (size_t)blk * DB * DB;
 
-    for (int e = tid; e < DB * DB; e += 256) {
-        int r = e % DB, cc = e / DB;
-        T v = Tr<T>::zero();
-        if (r < nb && cc < nb && r <= cc) v = Ublk[(size_t)r + (size_t)cc * ldu];
-        else if (r == cc) v = Tr<T>::one();
-        a[r + cc * DBL] = v;
-    }
-    __syncthreads();
+    T u[4][4], x[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r = 4 * tr + i, cc = 4 * tc + j;
+            T v = Tr<T>::zero();
+            if (r < nb && cc < nb && r <= cc) v = Ublk[(size_t)r + (size_t)cc * ldu];
+            else if (r == cc) v = Tr<T>::one();
+            u[i][j] = v;
+            x[i][j] = (r == cc) ? Tr<T>::one() : Tr<T>::zero();
+        }
 
     if (do_chol) {
-        for (int j = 0; j < nb; ++j) {
-            if (tid == 0) {
-                double d = real_(a[j + j * DBL]);
-                if (!(d > 0.0)) {
-                    atomicCAS(info, 0, k0 + j + 1);
-                    d = 1.0;
-                }
-                piv = sqrt(d);
-                a[j + j * DBL] = Tr<T>::make(piv, 0.0);
+        for (int j = 0; j < DB; ++j) {
+            const int jb = j >> 2, jj = j & 3, buf = j & 1;
+            if (tr == jb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == jj) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = u[i][q];
+                    }
             }
             __syncthreads();
-            double inv_p = 1.0 / piv;
-            for (int cc = j + 1 + tid; cc < nb; cc += 256) a[j + cc * DBL] = a[j + cc * DBL] * inv_p;
-            __syncthreads();
-            int rem = nb - j - 1;
-            for (int e = tid; e < rem * rem; e += 256) {
-                int r = j + 1 + e % rem, cc = j + 1 + e / rem;
-                if (r <= cc) {
-                    T v = a[r + cc * DBL];
-                    T t = Tr<T>::zero();
-                    fmac_(t, a[j + r * DBL], a[j + cc * DBL]);
-                    a[r + cc * DBL] = v - t;
-                }
+            double d = real_(rowb[buf][j]);
+            if (!(d > 0.0)) {
+                if (tid == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
+                d = 1.0;
             }
-            __syncthreads();
+            const double piv = sqrt(d), ipiv = 1.0 / piv;
+            T uc[4], ur[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
+                ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int r = 4 * tr + i, cc = 4 * tc + q;
+                    if (r == j) {
+                        if (cc > j) u[i][q] = uc[q];
+                        else if (cc == j) u[i][q] = Tr<T>::make(piv, 0.0);
+                    } else if (r > j && cc >= r) {
+                        T t = Tr<T>::zero();
+                        fmac_(t, ur[i], uc[q]);
+                        u[i][q] = u[i][q] - t;
+                    }
+                }
         }
-        for (int e = tid; e < nb * nb; e += 256) {
-            int r = e % nb, cc = e / nb;
-            if (r <= cc) Ublk[(size_t)r + (size_t)cc * ldu] = a[r + cc * DBL];
-        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int r = 4 * tr + i, cc = 4 * tc + q;
+                if (r < nb && cc < nb && r <= cc) Ublk[(size_t)r + (size_t)cc * ldu] = u[i][q];
+            }
         __syncthreads();
     }
 
-    // in-place inverse of the upper triangular a (LAPACK ?trti2 'U','N' order)
-    for (int j = 0; j < DB; ++j) {
-        if (tid < DB) colv[tid] = (tid < j) ? a[tid + j * DBL] : Tr<T>::zero();
-        __syncthreads();
-        T ajj;
-        {
-            T d = a[j + j * DBL];
-            double den = abs2_(d);
-            ajj = conj_(d) * (1.0 / den);  // 1/d
+    // X = U^-1 by right-looking back substitution on the rows, bottom up
+    for (int i2 = DB - 1; i2 >= 0; --i2) {
+        const int ib = i2 >> 2, ii = i2 & 3, buf = i2 & 1;
+        if (tr == ib) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i == ii) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = x[i][q];
+                }
         }
-        if (tid < j) {
-            T s = Tr<T>::zero();
-            for (int k = tid; k < j; ++k) fma_(s, a[tid + k * DBL], colv[k]);
-            a[tid + j * DBL] = -(s * ajj);
+        if (tc == ib) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q == ii) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colb[buf][4 * tr + i] = u[i][q];
+                }
         }
         __syncthreads();
-        if (tid == 0) a[j + j * DBL] = ajj;
-        __syncthreads();
+        T dgn = colb[buf][i2];
+        T dinv = conj_(dgn) * (1.0 / abs2_(dgn));
+        T xr[4], uc2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)
+            uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int r = 4 * tr + i, cc = 4 * tc + q;
+                if (r == i2) x[i][q] = xr[q];
+                else if (r < i2 && cc >= i2) {
+                    T t = Tr<T>::zero();
+                    fma_(t, uc2[i], xr[q]);
+                    x[i][q] = x[i][q] - t;
+                }
+            }
     }
-    for (int e = tid; e < DB * DB; e += 256) {
-        int r = e % DB, cc = e / DB;
-        inv[r + cc * DB] = (r <= cc) ? a[r + cc * DBL] : Tr<T>::zero();
-    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int r = 4 * tr + i, cc = 4 * tc + q;
+            inv[r + cc * DB] = (r <= cc) ? x[i][q] : Tr<T>::zero();
+        }
 }
 
 // A_kk <- invU^H * Herm(A_kk) * invU for one diagonal block (upper triangle in/out, real diagonal).

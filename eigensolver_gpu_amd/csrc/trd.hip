@@ -43,6 +43,7 @@ template <class T> struct PanelArgs {
     int nblkA;         // row-kernel workgroups that produced NP for column i
     int gh;            // hemv workgroups used for the column being finished / generated
     int nchunk;        // gemv row chunks for that column
+    int ablate;        // debug/timing only (EIGSOLVE_ABLATE): skips parts of the row kernel, results invalid
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -125,11 +126,11 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
     if (do_finish) {
         if (tid < 2 * NBMAX) {
             int which = tid >> 6, kk = tid & 63;
-            if (kk < npo)
+            if (kk < npo && !(a.ablate & 4))
                 for (int ch = 0; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
         }
-        for (int q = tid; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
-        if (do_update && wave == 0) {
+        if (!(a.ablate & 4)) for (int q = tid; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
+        if (do_update && wave == 0 && !(a.ablate & 8)) {
             if (lane < npo) {
                 int k = c + 1 + lane;
                 wi_w = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
 #pragma unroll
             for (int u = 0; u < RU; ++u) {
                 int kk = g + RG * u;
-                if (kk < npo) {
+                if (kk < npo && !(a.ablate & 1)) {
                     int k = c + 1 + kk;
                     vv[u] = a.A[(size_t)r + (size_t)k * a.lda];
                     wv[u] = a.W[(size_t)r + (size_t)(k - wbase) * a.ldw];
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
 #pragma unroll
             for (int u = 0; u < RP; ++u) {
                 int q = g + RG * u;
-                if (q < ntc) pp[u] = a.P[(size_t)q * a.ldp + r];
+                if (q < ntc && !(a.ablate & 2)) pp[u] = a.P[(size_t)q * a.ldp + r];
             }
             for (int q = g + RG * RP; q < ntc; q += RG) pp[0] = pp[0] + a.P[(size_t)q * a.ldp + r];
             if (g == 0) vr = a.A[(size_t)r + (size_t)c * a.lda];
@@ -559,7 +560,7 @@ template <class T> __global__ void __launch_bounds__(256) diag_extract_kernel(in
 static int hemv_grid(const Ctx& c, int n) {
     int nt = (n + HT - 1) / HT;
     long ntiles = (long)nt * (nt + 1) / 2;
-    long cap = c.hemv_blocks > 0 ? c.hemv_blocks : 4L * c.n_cu;
+    long cap = c.hemv_blocks > 0 ? c.hemv_blocks : 2L * c.n_cu;  // = resident workgroups (253 VGPRs -> 2 per CU): one wave of blocks, no tail
     return (int)(ntiles < cap ? ntiles : cap);
 }
 
@@ -589,6 +590,8 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
     PanelArgs<T> a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = e; a.tau = tau;
     a.xbuf = sc.xbuf; a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp; a.NP = sc.NP; a.alphaSlot = sc.alphaSlot;
+    static const int ablate_env = getenv("EIGSOLVE_ABLATE") ? atoi(getenv("EIGSOLVE_ABLATE")) : 0;
+    a.ablate = ablate_env;
     int gh_prev = 0, nchunk_prev = 0;
     for (int i = np - 1; i >= np - nb - 1; --i) {
         const bool last = (i == np - nb - 1);  // finish-only pass for the panel's leftmost column
@@ -669,7 +672,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     PanelArgs<T> a;
     a.A = const_cast<T*>(A); a.lda = lda; a.W = nullptr; a.ldw = 0; a.np = n + 1; a.nb = 1; a.i = n;
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
-    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
+    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0; a.ablate = 0;
     a.gh = hemv_grid(c, n);
     hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(256), 0, st, a, 1, 0);
     if (gather) {
