@@ -35,31 +35,24 @@ template <class T> struct GemmArgs {
 
 template <class T>
 __device__ __forceinline__ T fetch(const Operand<T>& o, int idx, int k, int nidx, int kend) {
-    T v = Tr<T>::zero();
-    if (idx < nidx && k < kend) {
-        const T* p = o.p;
-        int ld = o.ld, kk = k;
-        if (k >= o.k1) {
-            p = o.p2; ld = o.ld2; kk = k - o.k1;
-        }
-        int sr = o.trans ? kk : idx;
-        int sc = o.trans ? idx : kk;
-        bool keep = true, one = false;
-        if (o.mask == M_UPPER) keep = sr <= sc;
-        else if (o.mask == M_SUPPER) keep = sr < sc;
-        else if (o.mask == M_LOWER) keep = sr >= sc;
-        else if (o.mask == M_UNITTRAP) {
-            int d = sr - sc - o.moff;
-            keep = d < 0; one = (d == 0);
-        }
-        if (keep) {
-            v = p[(size_t)sr + (size_t)sc * ld];
-            if (o.conj) v = conj_(v);
-        } else if (one) {
-            v = Tr<T>::one();
-        }
+    // branch-free (see fetch_fast): always load from a clamped valid address, then select
+    bool keep = idx < nidx && k < kend, one = false;
+    const bool seg2 = k >= o.k1;
+    const T* p = seg2 ? o.p2 : o.p;
+    const int ld = seg2 ? o.ld2 : o.ld;
+    const int kk = seg2 ? k - o.k1 : k;
+    const int sr = o.trans ? kk : idx;
+    const int sc = o.trans ? idx : kk;
+    if (o.mask != M_NONE) {
+        const int d = sr - sc - o.moff;
+        const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
+        one = keep && (o.mask == M_UNITTRAP) && (d == 0);
+        keep = keep && km;
     }
-    return v;
+    const T* addr = keep ? p + (size_t)sr + (size_t)sc * ld : o.p;
+    T v = *addr;
+    if (o.conj) v = conj_(v);
+    return keep ? v : (one ? Tr<T>::one() : Tr<T>::zero());
 }
 
 // Restrict [kbeg,kend) to where a masked operand tile can be non-zero (skips the zero half of
@@ -78,7 +71,7 @@ __device__ __forceinline__ void trim_k(const Operand<T>& o, int i0, int bsz, int
 }
 
 constexpr int BKL = 16;  // K-slab of the large tiles (register-prefetch pipelined)
-constexpr int BKS = 64;  // K-slab of the small tiles: K <= 64 (trsm/larfb/panel-sized products) is ONE stage
+constexpr int BKS = 32;  // K-slab of the small tiles: K <= 64 (trsm/larfb/panel-sized products) is ONE stage
 
 #ifndef EIG_MFMA444
 #define EIG_MFMA444 1
@@ -268,6 +261,232 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_fast_kernel: same math and LDS layouts as gemm_kernel, restructured for throughput:
+//  * per-thread element descriptors (pointer, stored coordinates, validity) are computed ONCE;
+//    a stage costs one pointer bump, a mask compare and a load per element instead of the generic
+//    fetch() (which re-derives everything and was ~half of a stage's time);
+//  * K-concatenated operands (her2k) run as two phases over (p, ld) then (p2, ld2) -- the host
+//    guarantees k1 % BK == 0, otherwise the generic kernel is used;
+//  * LDS is double-buffered: the store of slab k+1 and the global loads of slab k+2 are issued
+//    before the MFMAs of slab k, ONE barrier per stage.
+// ------------------------------------------------------------------------------------------------
+template <class T> struct ElemDesc {
+    const T* p;   // address of X(idx, k = kloc) of the current segment
+    int sidx;     // stored-row (trans=0) / stored-col (trans=1) coordinate = global idx
+    int kloc;     // k offset of this element inside a slab
+    bool ok;      // idx in range
+};
+
+// Branch-free: the load is ALWAYS issued (from a clamped, valid address) and the value selected
+// afterwards.  With `if (ok) v = *p` hipcc puts every load in its own basic block followed by
+// s_waitcnt vmcnt(0) -- the loads of a slab then complete one after the other (measured: 66 % of
+// the wave cycles in waits).
+template <class T, bool MASKED>
+__device__ __forceinline__ T fetch_fast(const Operand<T>& o, const ElemDesc<T>& e, const T* safe, long kstride, int k, int kend) {
+    const int kk = k + e.kloc;
+    bool keep = e.ok && kk < kend, one = false;
+    if (MASKED && o.mask != M_NONE) {
+        const int sr = o.trans ? kk : e.sidx;
+        const int sc = o.trans ? e.sidx : kk;
+        const int d = sr - sc - o.moff;
+        const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
+        one = keep && (o.mask == M_UNITTRAP) && (d == 0);
+        keep = keep && km;
+    }
+    const T* addr = keep ? e.p + (long)k * kstride : safe;
+    T v = *addr;
+    if (o.conj) v = conj_(v);
+    return keep ? v : (one ? Tr<T>::one() : Tr<T>::zero());
+}
+
+template <class T, int BM, int BN, int TA, int TB, int BK, bool MASKED>
+__global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
+    constexpr bool CX = Tr<T>::cx;
+    constexpr int NPL = CX ? 2 : 1;
+    constexpr int LDA = TA == 0 ? BM + 16 : BK + 2;
+    constexpr int LDB = TB == 0 ? BN + 16 : BK + 2;
+    constexpr int ASZ = TA == 0 ? BK * LDA : BM * LDA;
+    constexpr int BSZ = TB == 0 ? BK * LDB : BN * LDB;
+    constexpr int STG = NPL * (ASZ + BSZ);   // doubles per LDS stage
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    __shared__ double sm[2 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
+    if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
+
+    int kbeg = 0, kend = g.K;
+    if (g.kchunk > 0) {
+        kbeg = blockIdx.z * g.kchunk;
+        kend = min(g.K, kbeg + g.kchunk);
+    }
+    trim_k(g.A, i0, BM, kbeg, kend);
+    trim_k(g.B, j0, BN, kbeg, kend);
+    kbeg &= ~(BK - 1);
+
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    d4 acc[NPL][TM][TN];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
+
+    // ---- element descriptors -----------------------------------------------------------------------
+    ElemDesc<T> ea[EA], eb[EB];
+    int offa[EA], offb[EB];   // LDS offsets inside a stage
+    const long ksa = g.A.trans ? 1 : (long)g.A.ld, ksb = g.B.trans ? 1 : (long)g.B.ld;
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+        int idx, k;
+        if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
+        else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+        ea[e].sidx = i0 + idx; ea[e].kloc = k; ea[e].ok = (i0 + idx) < g.M;
+        ea[e].p = g.A.trans ? g.A.p + (size_t)k + (size_t)(i0 + idx) * g.A.ld : g.A.p + (size_t)(i0 + idx) + (size_t)k * g.A.ld;
+        offa[e] = TA == 0 ? k * LDA + idx : idx * LDA + k;
+    }
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        int idx, k;
+        if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
+        else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
+        eb[e].sidx = j0 + idx; eb[e].kloc = k; eb[e].ok = (j0 + idx) < g.N;
+        eb[e].p = g.B.trans ? g.B.p + (size_t)k + (size_t)(j0 + idx) * g.B.ld : g.B.p + (size_t)(j0 + idx) + (size_t)k * g.B.ld;
+        offb[e] = NPL * ASZ + (TB == 0 ? k * LDB + idx : idx * LDB + k);
+    }
+    // second segment (K-concatenation): same descriptors on (p2, ld2), logical k >= k1
+    const bool cat = g.A.k1 != INT_MAX;
+    const int k1 = cat ? g.A.k1 : kend;   // host guarantees A.k1 == B.k1 and k1 % BK == 0
+
+    T ra[EA], rb[EB];
+    auto gload = [&](int k0) {
+        if (!cat || k0 < k1) {
+#pragma unroll
+            for (int e = 0; e < EA; ++e) ra[e] = fetch_fast<T, MASKED>(g.A, ea[e], g.A.p, ksa, k0, min(kend, k1));
+#pragma unroll
+            for (int e = 0; e < EB; ++e) rb[e] = fetch_fast<T, MASKED>(g.B, eb[e], g.B.p, ksb, k0, min(kend, k1));
+        } else {
+            const long ks2a = g.A.trans ? 1 : (long)g.A.ld2, ks2b = g.B.trans ? 1 : (long)g.B.ld2;
+#pragma unroll
+            for (int e = 0; e < EA; ++e) {
+                ElemDesc<T> d = ea[e];
+                d.p = g.A.trans ? g.A.p2 + (size_t)d.kloc + (size_t)d.sidx * g.A.ld2 : g.A.p2 + (size_t)d.sidx + (size_t)d.kloc * g.A.ld2;
+                ra[e] = fetch_fast<T, MASKED>(g.A, d, g.A.p2, ks2a, k0 - k1, kend - k1);
+            }
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                ElemDesc<T> d = eb[e];
+                d.p = g.B.trans ? g.B.p2 + (size_t)d.kloc + (size_t)d.sidx * g.B.ld2 : g.B.p2 + (size_t)d.sidx + (size_t)d.kloc * g.B.ld2;
+                rb[e] = fetch_fast<T, MASKED>(g.B, d, g.B.p2, ks2b, k0 - k1, kend - k1);
+            }
+        }
+    };
+    auto lstore = [&](double* st) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            st[offa[e]] = real_(ra[e]);
+            if (CX) st[ASZ + offa[e]] = imag_(ra[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            st[offb[e]] = real_(rb[e]);
+            if (CX) st[BSZ + offb[e]] = imag_(rb[e]);
+        }
+    };
+
+    const int fi = lane & 15, fk = lane >> 4;
+    const int nst = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    if (nst > 0) {
+        gload(kbeg);
+        lstore(sm);
+        if (nst > 1) gload(kbeg + BK);
+        __syncthreads();
+    }
+    for (int s_ = 0; s_ < nst; ++s_) {
+        const double* As = sm + (s_ & 1) * STG;
+        const double* Bs = As + NPL * ASZ;
+        if (s_ + 1 < nst) {
+            lstore(sm + ((s_ + 1) & 1) * STG);                 // slab s+1 (registers) -> other buffer
+            if (s_ + 2 < nst) gload(kbeg + (s_ + 2) * BK);     // slab s+2 in flight during the MFMAs
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double ar[TM], ai[TM], br[TN][4], bi[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                int m = wm0 + a * 16 + fi, k = kk + fk;
+                int off = TA == 0 ? k * LDA + m : m * LDA + k;
+                ar[a] = As[off];
+                if (CX) ai[a] = As[ASZ + off];
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int n = wn0 + b * 16 + 4 * r + (lane & 3), k = kk + fk;
+                    int off = TB == 0 ? k * LDB + n : n * LDB + k;
+                    br[b][r] = Bs[off];
+                    if (CX) bi[b][r] = Bs[BSZ + off];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ar[a], acc[0][a][b][r], 0, 0, 0);
+                        if (CX) acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ar[a], acc[NPL - 1][a][b][r], 0, 0, 0);
+                    }
+                }
+            }
+            if (CX) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ai[a], acc[0][a][b][r], 0, 0, 1);
+                            acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ai[a], acc[NPL - 1][a][b][r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int gi = i0 + wm0 + a * 16 + fi;
+                int gj = j0 + wn0 + b * 16 + fk + 4 * r;
+                if (gi >= g.M || gj >= g.N) continue;
+                if (g.epi.uplo == 1 && gi > gj) continue;
+                if (g.epi.uplo == 2 && gi < gj) continue;
+                T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
+                if (g.kchunk > 0) {
+                    g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
+                } else {
+                    T* cp = g.C + (size_t)gi + (size_t)gj * g.ldc;
+                    T out = g.alpha * v;
+                    if (!(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0)) out = out + g.beta * (*cp);
+                    if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
+                    *cp = out;
+                }
+            }
+        }
+    }
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int splits, const T* P, size_t pstride, T alpha,
                                                             T beta, T* C, int ldc, Epi epi) {
@@ -285,12 +504,31 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
     *cp = out;
 }
 
+static bool g_use_fast = getenv("EIGSOLVE_GEMM_GENERIC") == nullptr;
+
 template <class T, int BM, int BN>
 static void launch_gemm(hipStream_t st, const GemmArgs<T>& g, int splits) {
     constexpr int BK = (BM * BN <= 64 * 32) ? BKS : BKL;
     dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
     dim3 block(256);
     int ta = g.A.trans, tb = g.B.trans;
+    const bool cat = g.A.k1 != INT_MAX || g.B.k1 != INT_MAX;
+    const bool cat_ok = !cat || (g.A.k1 == g.B.k1 && g.A.k1 % BK == 0);
+    if (g_use_fast && cat_ok) {
+        const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
+#define EIG_LAUNCH_FAST(TA_, TB_)                                                                                        \
+    do {                                                                                                                 \
+        if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, 0, st, g);        \
+        else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, false>), grid, block, 0, st, g);              \
+    } while (0)
+        if (ta == 0 && tb == 0) EIG_LAUNCH_FAST(0, 0);
+        else if (ta == 0 && tb == 1) EIG_LAUNCH_FAST(0, 1);
+        else if (ta == 1 && tb == 0) EIG_LAUNCH_FAST(1, 0);
+        else EIG_LAUNCH_FAST(1, 1);
+#undef EIG_LAUNCH_FAST
+        EIG_HIP(hipGetLastError());
+        return;
+    }
     if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 0, BK>), grid, block, 0, st, g);
     else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 1, BK>), grid, block, 0, st, g);
     else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 0, BK>), grid, block, 0, st, g);
