@@ -124,19 +124,43 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
 #pragma unroll
     for (int u = 0; u < RP; ++u) pp[u] = Tr<T>::zero();
     if (do_finish) {
+        // independent, branch-free loads (a `for (...) s += x[q]` loop is a chain of dependent round trips)
         if (tid < 2 * NBMAX) {
             int which = tid >> 6, kk = tid & 63;
-            if (kk < npo && !(a.ablate & 4))
-                for (int ch = 0; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
+            if (kk < npo) {
+                T zt[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int ch = min(u, a.nchunk - 1);
+                    T t = a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
+                    zt[u] = (u < a.nchunk) ? t : Tr<T>::zero();
+                }
+                for (int ch = 8; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) zs = zs + zt[u];
+            }
         }
-        if (!(a.ablate & 4)) for (int q = tid; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
-        if (do_update && wave == 0 && !(a.ablate & 8)) {
+        {
+            T st4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int q = tid + 256 * u;
+                T t = a.S[min(q, a.gh - 1)];
+                st4[u] = (q < a.gh) ? t : Tr<T>::zero();
+            }
+            for (int q = tid + 1024; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
+            Ssum = Ssum + ((st4[0] + st4[1]) + (st4[2] + st4[3]));
+        }
+        if (do_update && wave == 0) {
             if (lane < npo) {
                 int k = c + 1 + lane;
                 wi_w = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
                 wi_v = a.A[(size_t)i + (size_t)k * a.lda];
             }
-            for (int q = lane; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];
+            T p0 = a.P[(size_t)min(lane, ntc - 1) * a.ldp + i];
+            T p1 = a.P[(size_t)min(lane + 64, ntc - 1) * a.ldp + i];
+            wi_p = ((lane < ntc) ? p0 : Tr<T>::zero()) + ((lane + 64 < ntc) ? p1 : Tr<T>::zero());
+            for (int q = lane + 128; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];
         }
         if (active) {
 #pragma unroll
@@ -372,8 +396,15 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
     // ---------------- scalar prologue (every workgroup, deterministic) ----------------
     if (!plain) {
         if (wave == 0) {
-            double ss = 0.0;
-            for (int q = lane; q < a.nblkA; q += 64) ss += a.NP[q];
+            double ss = 0.0, np4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int q = lane + 64 * u;
+                double t = a.NP[min(q, a.nblkA - 1)];
+                np4[u] = (q < a.nblkA) ? t : 0.0;
+            }
+            for (int q = lane + 256; q < a.nblkA; q += 64) ss += a.NP[q];
+            ss += (np4[0] + np4[1]) + (np4[2] + np4[3]);
             ss = wave_sum(ss);
             if (lane == 0) {
                 double beta;
