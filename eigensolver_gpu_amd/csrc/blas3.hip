@@ -642,6 +642,8 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
             x[i][j] = (r == cc) ? Tr<T>::one() : Tr<T>::zero();
         }
 
+    const bool upper_blk = tc >= tr;   // only blocks on or above the block diagonal carry data
+    const bool diag_blk = tc == tr;
     if (do_chol) {
         for (int j = 0; j < DB; ++j) {
             const int jb = j >> 2, jj = j & 3, buf = j & 1;
@@ -659,27 +661,40 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                 if (tid == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
                 d = 1.0;
             }
-            const double piv = sqrt(d), ipiv = 1.0 / piv;
-            T uc[4], ur[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
-                ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+            if (upper_blk && tr >= jb) {   // rows >= j only; roles are static inside a block phase
+                const double piv = sqrt(d), ipiv = 1.0 / piv;
+                T uc[4], ur[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    int r = 4 * tr + i, cc = 4 * tc + q;
-                    if (r == j) {
-                        if (cc > j) u[i][q] = uc[q];
-                        else if (cc == j) u[i][q] = Tr<T>::make(piv, 0.0);
-                    } else if (r > j && cc >= r) {
-                        T t = Tr<T>::zero();
-                        fmac_(t, ur[i], uc[q]);
-                        u[i][q] = u[i][q] - t;
-                    }
+                    uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
+                    ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
                 }
+                if (tr > jb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (!diag_blk || q >= i) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], uc[q]);
+                                u[i][q] = u[i][q] - t;
+                            }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (i == jj) {
+                                if (!diag_blk || q > jj) u[i][q] = uc[q];
+                                else if (q == jj) u[i][q] = Tr<T>::make(piv, 0.0);
+                            } else if (i > jj && (!diag_blk || q >= i)) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], uc[q]);
+                                u[i][q] = u[i][q] - t;
+                            }
+                        }
+                }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -711,26 +726,38 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                 }
         }
         __syncthreads();
-        T dgn = colb[buf][i2];
-        T dinv = conj_(dgn) * (1.0 / abs2_(dgn));
-        T xr[4], uc2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)
-            uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        if (upper_blk && tr <= ib && tc >= ib) {   // rows <= i2, columns >= i2
+            T dgn = colb[buf][i2];
+            T dinv = conj_(dgn) * (1.0 / abs2_(dgn));
+            T xr[4], uc2[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                int r = 4 * tr + i, cc = 4 * tc + q;
-                if (r == i2) x[i][q] = xr[q];
-                else if (r < i2 && cc >= i2) {
-                    T t = Tr<T>::zero();
-                    fma_(t, uc2[i], xr[q]);
-                    x[i][q] = x[i][q] - t;
-                }
+                xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)   (zero for c < i2)
+                uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
             }
+            if (tr < ib) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        T t = Tr<T>::zero();
+                        fma_(t, uc2[i], xr[q]);
+                        x[i][q] = x[i][q] - t;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (i == ii) x[i][q] = xr[q];
+                        else if (i < ii) {
+                            T t = Tr<T>::zero();
+                            fma_(t, uc2[i], xr[q]);
+                            x[i][q] = x[i][q] - t;
+                        }
+                    }
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
