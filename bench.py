@@ -195,7 +195,9 @@ def main():
         tp = os.path.join(ROOT, "profiles", "hemv_traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+                # PMC FETCH_SIZE/WRITE_SIZE were collected on single n=4096 launches (a PMC pass over a whole
+                # solve takes >30 min); the measured traffic/algorithmic ratio is applied to this run's bytes.
+                traffic = json.load(open(tp)).get("traffic_over_algorithmic") * per_launch_bytes
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "panel_mv_kernel (hemv+stacked gemv), %d launches of one hetrd N=%d" % (r["launches"], n),
