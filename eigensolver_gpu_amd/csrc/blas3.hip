@@ -461,6 +461,25 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
         __syncthreads();
     }
 
+    // epilogue, branch-free on the load side: all C reads of the tile are issued together (clamped
+    // addresses), then combined and stored under a predicate.  (`if (valid) { load; store; }` per
+    // element serialises 16 dependent round trips -- the same hipcc pattern as in the operand loads.)
+    const bool use_c = g.kchunk == 0 && !(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0);
+    T cv[TM][TN][4];
+    if (use_c) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int gi = i0 + wm0 + a * 16 + fi;
+                    int gj = j0 + wn0 + b * 16 + fk + 4 * r;
+                    bool ok = gi < g.M && gj < g.N;
+                    const T* cp = ok ? g.C + (size_t)gi + (size_t)gj * g.ldc : g.C;
+                    cv[a][b][r] = *cp;
+                }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -469,18 +488,17 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
             for (int r = 0; r < 4; ++r) {
                 int gi = i0 + wm0 + a * 16 + fi;
                 int gj = j0 + wn0 + b * 16 + fk + 4 * r;
-                if (gi >= g.M || gj >= g.N) continue;
-                if (g.epi.uplo == 1 && gi > gj) continue;
-                if (g.epi.uplo == 2 && gi < gj) continue;
+                bool ok = gi < g.M && gj < g.N;
+                if (g.epi.uplo == 1 && gi > gj) ok = false;
+                if (g.epi.uplo == 2 && gi < gj) ok = false;
                 T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
                 if (g.kchunk > 0) {
-                    g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
+                    if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
                 } else {
-                    T* cp = g.C + (size_t)gi + (size_t)gj * g.ldc;
                     T out = g.alpha * v;
-                    if (!(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0)) out = out + g.beta * (*cp);
+                    if (use_c) out = out + g.beta * cv[a][b][r];
                     if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
-                    *cp = out;
+                    if (ok) g.C[(size_t)gi + (size_t)gj * g.ldc] = out;
                 }
             }
         }
@@ -551,6 +569,8 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
         else launch_gemm<T, 32, 64>(st, g, splits);
         return;
     }
+    static const int tile_knob = getenv("EIGSOLVE_GEMM_TILE") ? atoi(getenv("EIGSOLVE_GEMM_TILE")) : 0;  // experiments only
+    if (tile_knob == 32) { launch_gemm<T, 32, 32>(st, g, splits); return; }
     if constexpr (Tr<T>::cx) {
         if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
         else launch_gemm<T, 32, 32>(st, g, splits);
