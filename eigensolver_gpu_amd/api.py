@@ -88,8 +88,11 @@ def _p(t):
 
 
 def _sync():
+    """Inputs produced by torch kernels must be complete before the library's own stream touches them.
+    Only the calling thread's current torch stream is synchronised (NOT the device): several host threads
+    may drive independent solves on the same GPU concurrently (one context per (thread, device))."""
     import torch
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()
 
 
 # ---- module eigsolve_vars -------------------------------------------------------------------------
