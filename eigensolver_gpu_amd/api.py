@@ -366,3 +366,25 @@ def stedc_device(d, e):
     ms = ctypes.c_double(0)
     rc = lib().eigsolve_dstedc_device(c_int(N), _p(dd), _p(ed), _p(w), _p(Q), c_int(N), ctypes.byref(ms))
     return rc, w.cpu().numpy(), to_host(Q), ms.value
+
+
+def heevd(A_d, il, iu, ws=None):
+    """zheevd_gpu / dsyevd_gpu (zheevd_gpu.F90:32-134): standard problem A z = w z, jobz='V', uplo='U',
+    eigenpairs il..iu.  A_d (upper triangle) is overwritten with the reflectors.  Returns (info, ws)."""
+    import torch
+    _sync()
+    N = A_d.shape[0]
+    cx = A_d.dtype == torch.complex128
+    if ws is None:
+        ws = Workspace(N, cx)
+    info = c_int(0)
+    if cx:
+        lib().eigsolve_zheevd(c_int(il), c_int(iu), c_int(N), _p(A_d), c_int(A_d.shape[1]), _p(ws.Z), c_int(N), _p(ws.w),
+                              _p(ws.work), c_int(ws.lwork), _p(ws.rwork), c_int(ws.lrwork), _p(ws.work_h), c_int(ws.lwork_h),
+                              _p(ws.rwork_h), c_int(ws.lrwork_h), _p(ws.iwork_h), c_int(ws.liwork_h), _p(ws.Z_h), c_int(N),
+                              _p(ws.w_h), ctypes.byref(info))
+    else:
+        lib().eigsolve_dsyevd(c_int(il), c_int(iu), c_int(N), _p(A_d), c_int(A_d.shape[1]), _p(ws.Z), c_int(N), _p(ws.w),
+                              _p(ws.work), c_int(ws.lwork), _p(ws.work_h), c_int(ws.lwork_h), _p(ws.iwork_h),
+                              c_int(ws.liwork_h), _p(ws.Z_h), c_int(N), _p(ws.w_h), ctypes.byref(info))
+    return info.value, ws

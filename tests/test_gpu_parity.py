@@ -480,3 +480,28 @@ def test_full_spectrum_vs_lapack(env, cplx, fam):
     # Cholesky-based reduction: the backward error grows with cond(B) for LAPACK as well -> judge against it
     assert berr <= max(20 * n * EPS, 4 * berr_lap)
     assert oracle.compare_1d(wl, w)[0] <= (1e-12 if fam == "wc" else 1e-7)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,il,iu", [(3, 1, 3), (97, 1, 30), (300, 11, 40)])
+@pytest.mark.parametrize("tri", [0, 1])
+def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
+    """zheevd_gpu / dsyevd_gpu as a public stage routine (standard problem): device results only
+    (the reference's heevd leaves the host copy to its caller), eigenvalues vs LAPACK, residual, orthogonality."""
+    torch, oracle, api = env
+    import scipy.linalg as sl
+    A = oracle.gen_spd_fast(n, 3000 + n, cplx) - n / 4.0 * np.eye(n)   # indefinite on purpose
+    try:
+        api.set_option("tridiag", tri)
+        info, ws = api.heevd(api.to_device(np.triu(A)), il, iu)
+    finally:
+        api.set_option("tridiag", -1)
+    assert info == 0
+    m = iu - il + 1
+    w = ws.w.cpu().numpy()
+    Z = np.asfortranarray(api.to_host(ws.Z, n, m))
+    wl = sl.eigh(A, eigvals_only=True)
+    nrm = np.linalg.norm(A, 2)
+    assert np.abs(w - wl).max() <= 50 * n * EPS * nrm
+    assert np.abs(A @ Z - Z * w[il - 1:iu]).max() <= 50 * n * EPS * nrm
+    assert np.abs(Z.conj().T @ Z - np.eye(m)).max() <= 50 * n * EPS
