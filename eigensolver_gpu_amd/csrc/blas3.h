@@ -85,6 +85,11 @@ template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* 
 // A <- U^-H A U^-1 (upper triangle only is read/written).
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
+// potrf(B) and hegst(A, U) with the two launch chains overlapped on c.s1 / c.s2 at the top level of the
+// recursion: while s1 factors the trailing half of B, s2 already reduces the leading half of A (which only
+// needs U11, U12).  Joins on c.s1.  On a non-positive-definite B the upper triangle of A is unspecified.
+template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb);
+
 inline constexpr int kDiagBlk = 64;  // order of the inverted diagonal blocks
 
 }  // namespace eig

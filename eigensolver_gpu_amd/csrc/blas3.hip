@@ -980,6 +980,64 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     hegst_rec(c, st, N, 0, A, lda, U, ldu);
 }
 
+template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
+    hipStream_t s1 = c.s1, s2 = c.s2;
+    int nblk = (N + DB - 1) / DB;
+    T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), s1));
+    if (N <= 2 * DB) {
+        potrf_rec(c, s1, N, N, 0, B, ldb, invU);
+        hegst_rec(c, s1, N, 0, A, lda, (const T*)B, ldb);
+        return;
+    }
+    const int n1 = split_n1(N), n2 = N - n1;
+    T* B12 = B + (size_t)n1 * ldb;
+    T* B22 = B + (size_t)n1 + (size_t)n1 * ldb;
+    T* A12 = A + (size_t)n1 * lda;
+    T* A22 = A + (size_t)n1 + (size_t)n1 * lda;
+    const T mhalf = Tr<T>::make(-0.5, 0.0);
+    // s2 must not start before everything already queued on s1 (caller's data, the memset) is done
+    EIG_HIP(hipEventRecord(c.evA, s1));
+    EIG_HIP(hipStreamWaitEvent(s2, c.evA, 0));
+    // ---- s1: leading half of the Cholesky factor, then the off-diagonal block U12 -------------------------
+    potrf_rec(c, s1, N, n1, 0, B, ldb, invU);
+    trsm_LUC(c, s1, n1, n2, (const T*)B, ldb, 0, B12, ldb);
+    EIG_HIP(hipEventRecord(c.evB, s1));            // U11, U12, inv blocks of U11 ready
+    // ---- s1 continues: trailing half ------------------------------------------------------------------------
+    {
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        gemm<T>(c, s1, n2, n2, n1, Tr<T>::make(-1.0, 0.0), opA('C', (const T*)B12, ldb), opB('N', (const T*)B12, ldb),
+                Tr<T>::one(), B22, ldb, e);
+    }
+    potrf_rec(c, s1, N, n2, n1, B, ldb, invU);
+    // ---- s2: the part of hegst that only needs U11 and U12 (zhegst_gpu.F90:57-101 for the leading block) ----
+    EIG_HIP(hipStreamWaitEvent(s2, c.evB, 0));
+    hegst_rec(c, s2, n1, 0, A, lda, (const T*)B, ldb);
+    trsm_LUC(c, s2, n1, n2, (const T*)B, ldb, 0, A12, lda);
+    auto hemm_half = [&]() {
+        Operand<T> up = op_plain((const T*)A, lda, 0, 0);
+        up.mask = M_UPPER;
+        Operand<T> lo = op_plain((const T*)A, lda, 1, 1);
+        lo.mask = M_SUPPER;
+        gemm<T>(c, s2, n1, n2, n1, mhalf, up, opB('N', (const T*)B12, ldb), Tr<T>::one(), A12, lda);
+        gemm<T>(c, s2, n1, n2, n1, mhalf, lo, opB('N', (const T*)B12, ldb), Tr<T>::one(), A12, lda);
+    };
+    hemm_half();
+    {
+        Operand<T> Ao, Bo;
+        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = B12; Ao.ld2 = ldb;
+        Bo.p = B12; Bo.ld = ldb; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        gemm<T>(c, s2, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+    }
+    hemm_half();
+    EIG_HIP(hipEventRecord(c.evA, s2));
+    // ---- join on s1: the rest needs U22 ----------------------------------------------------------------------
+    EIG_HIP(hipStreamWaitEvent(s1, c.evA, 0));
+    trsm_RUN(c, s1, n2, n1, (const T*)B, ldb, n1, A12, lda);
+    hegst_rec(c, s1, n2, n1, A, lda, (const T*)B, ldb);
+}
+
 // explicit instantiations
 #define INST(T)                                                                                                          \
     template void gemm<T>(Ctx&, hipStream_t, int, int, int, T, const Operand<T>&, const Operand<T>&, T, T*, int, Epi);   \
@@ -991,7 +1049,8 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
     template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
     template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
-    template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);
+    template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \
+    template void potrf_hegst_overlapped<T>(Ctx&, int, T*, int, T*, int);
 INST(double)
 INST(cplx)
 

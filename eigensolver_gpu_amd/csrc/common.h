@@ -109,6 +109,16 @@ struct Ctx {
     int trd_nb = 64;
     int bt_nb = 64;
     int hemv_blocks = 0;  // 0 = auto
+    int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
+                             // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
+    int overlap = 0;         // 1: potrf || first half of gst, T factors || tridiagonal solve on the second stream.
+                             // Measured: -3 % latency of an isolated solve, but -15 % throughput with 2 solves in flight -> off
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        hipGraph_t graph = nullptr;
+        const void* ptrs[16] = {};
+    };
+    std::map<std::string, GraphEntry> graphs;
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
 
     template <class T> T* scratch(const char* name, size_t count) {

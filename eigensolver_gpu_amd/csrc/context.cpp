@@ -67,6 +67,11 @@ void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
 }
 
 void Ctx::release() {
+    for (auto& kv : graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    graphs.clear();
     for (auto& kv : slots)
         if (kv.second.first) (void)hipFree(kv.second.first);
     slots.clear();
@@ -103,6 +108,8 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c->trd_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_GRAPH")) c->use_graph = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
     if (c->bt_nb < 1 || c->bt_nb > 64) c->bt_nb = 64;
@@ -218,6 +225,8 @@ int eigsolve_set_option(const char* name, int value) {
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
+        else if (s == "graph") c.use_graph = value > 0;
+        else if (s == "overlap") c.overlap = value != 0;
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

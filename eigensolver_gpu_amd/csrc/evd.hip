@@ -60,15 +60,13 @@ template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, 
 // block costs three MFMA launches.  V's bottom square is masked on the fly (unit upper
 // triangular) instead of the reference's stash / zero / restore of A (:154-164, :203-211).
 template <class T>
-static void back_transform(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, const T* tau, T* Z, int ldz, int nb2) {
+static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const T* tau, int nb2) {
     const int k = N - 1;
-    if (k <= 0 || m <= 0) return;
+    if (k <= 0) return;
     if (nb2 > N) nb2 = N;
     const int nblk = (k + nb2 - 1) / nb2;
     const int ldt = 64;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
-    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 64);
-    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 64);
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
         const T* V = A + (size_t)(i + 1) * lda;
@@ -82,6 +80,18 @@ static void back_transform(Ctx& c, hipStream_t st, int N, int m, const T* A, int
     }
     hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
     EIG_HIP(hipGetLastError());
+}
+
+template <class T>
+static void bt_apply(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, T* Z, int ldz, int nb2) {
+    const int k = N - 1;
+    if (k <= 0 || m <= 0) return;
+    if (nb2 > N) nb2 = N;
+    const int nblk = (k + nb2 - 1) / nb2;
+    const int ldt = 64;
+    T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
+    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 64);
+    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 64);
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
         const T* V = A + (size_t)(i + 1) * lda;
@@ -133,8 +143,54 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     PhaseTimer pt(c);
     const int m = iu - il + 1;
     pt.begin(PH_TRD);
-    hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
+    const T* Vsrc = A;      // where the reflectors live for the back-transformation
+    int ldv = lda;
+    const T* tau_bt = tau_d;
+    if (c.use_graph && N > 64) {
+        // hipGraph path: fixed-address internal working set, launch sequence captured once per (type, N).
+        const size_t NN = (size_t)N * N;
+        T* Aw = c.scratch<T>(Tr<T>::cx ? "g_Az" : "g_Ad", NN);
+        T* Ww = c.scratch<T>(Tr<T>::cx ? "g_Wz" : "g_Wd", (size_t)N * 64);
+        T* tauw = c.scratch<T>(Tr<T>::cx ? "g_tauz" : "g_taud", (size_t)N + 8);
+        double* dw = c.scratch<double>(Tr<T>::cx ? "g_dz" : "g_dd", (size_t)N + 8);
+        double* ew = c.scratch<double>(Tr<T>::cx ? "g_ez" : "g_ed", (size_t)N + 8);
+        const void* cur[16] = {};
+        (void)hemv_scratch_touch<T>(c, N, cur + 5);   // all scratch used inside the captured region exists before capture
+        cur[0] = Aw; cur[1] = Ww; cur[2] = tauw; cur[3] = dw; cur[4] = ew;
+        char key[64];
+        snprintf(key, sizeof key, "trd_%c_%d_%d_%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks);
+        Ctx::GraphEntry& ge = c.graphs[key];
+        bool valid = ge.exec != nullptr;
+        for (int q = 0; q < 16 && valid; ++q) valid = (ge.ptrs[q] == cur[q]);
+        if (!valid) {
+            if (ge.exec) { (void)hipGraphExecDestroy(ge.exec); ge.exec = nullptr; }
+            if (ge.graph) { (void)hipGraphDestroy(ge.graph); ge.graph = nullptr; }
+            EIG_HIP(hipStreamSynchronize(st));
+            EIG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            hetrd_upper<T>(c, st, N, Aw, N, dw, ew, tauw, Ww, c.trd_nb);
+            EIG_HIP(hipStreamEndCapture(st, &ge.graph));
+            EIG_HIP(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+            for (int q = 0; q < 16; ++q) ge.ptrs[q] = cur[q];
+        }
+        EIG_HIP(hipMemcpy2DAsync(Aw, sizeof(T) * N, A, sizeof(T) * lda, sizeof(T) * N, N, hipMemcpyDeviceToDevice, st));
+        EIG_HIP(hipGraphLaunch(ge.exec, st));
+        EIG_HIP(hipMemcpyAsync(w_d, dw, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
+        if (N > 1) EIG_HIP(hipMemcpyAsync(e_d, ew, sizeof(double) * (N - 1), hipMemcpyDeviceToDevice, st));
+        EIG_HIP(hipMemcpyAsync(tau_d, tauw, sizeof(T) * (N - 1), hipMemcpyDeviceToDevice, st));
+        Vsrc = Aw; ldv = N; tau_bt = tauw;
+    } else {
+        hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
+    }
     pt.end(PH_TRD);
+    // larft T factors depend only on the reflectors: build them on the second stream while the tridiagonal
+    // eigenproblem is being solved (zheevd_gpu.F90:125 does the same per block with stream1/stream2)
+    hipStream_t stT = c.overlap ? c.s2 : st;
+    if (c.overlap) {
+        EIG_HIP(hipEventRecord(c.evA, st));
+        EIG_HIP(hipStreamWaitEvent(stT, c.evA, 0));
+        bt_build_T<T>(c, stT, N, Vsrc, ldv, tau_bt, c.bt_nb);
+        EIG_HIP(hipEventRecord(c.evB, stT));
+    }
     if (c.tridiag_device) {
         // device-side divide & conquer: no N x N host round trip at all
         EIG_HIP(hipStreamSynchronize(st));
@@ -183,7 +239,9 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     c.phase_ms[PH_STEDC] += now_ms() - t0;
     }
     pt.begin(PH_BT);
-    back_transform<T>(c, st, N, m, A, lda, tau_d, Z, ldz, c.bt_nb);
+    if (c.overlap) EIG_HIP(hipStreamWaitEvent(st, c.evB, 0));
+    else bt_build_T<T>(c, st, N, Vsrc, ldv, tau_bt, c.bt_nb);
+    bt_apply<T>(c, st, N, m, Vsrc, ldv, Z, ldz, c.bt_nb);
     pt.end(PH_BT);
     return 0;
 }
@@ -202,6 +260,22 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     clear_phases(c);
     double t_all = now_ms();
     const int m = iu - il + 1;
+    if (c.overlap) {
+        // potrf || leading half of gst on two streams (both are chains of small dependent launches); phase
+        // times: "potrf" = until the factor is complete, "gst" = the non-overlapped remainder.
+        pt.begin(PH_POTRF);
+        potrf_hegst_overlapped<T>(c, N, A, lda, B, ldb);
+        pt.end(PH_POTRF);
+        EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+        EIG_HIP(hipStreamSynchronize(st));
+        pt.collect(PH_POTRF);
+        if (c.h_info[0] != 0) {
+            printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
+            return -1;
+        }
+        pt.begin(PH_GST);
+        pt.end(PH_GST);
+    } else {
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
     pt.begin(PH_POTRF);
     potrf_upper<T>(c, st, N, B, ldb);
@@ -218,6 +292,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     pt.begin(PH_GST);
     hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
     pt.end(PH_GST);
+    }
     int info = heevd_core<T>(c, il, iu, N, A, lda, Z, ldz, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork, lswork, iwork,
                              liwork);  // :163
     if (info != 0) return -1;

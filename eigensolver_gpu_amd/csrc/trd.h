@@ -17,4 +17,8 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
 template <class T>
 void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes);
 
+// Allocates (if needed) every scratch slot hetrd_upper uses for order N and returns one of the pointers
+// (graph capture must not allocate; the pointer doubles as a cache-validity token).
+template <class T> const void* hemv_scratch_touch(Ctx& c, int N, const void** all6 = nullptr);
+
 }  // namespace eig

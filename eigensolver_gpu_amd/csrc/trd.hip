@@ -715,6 +715,15 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
 
 template void hetrd_upper<double>(Ctx&, hipStream_t, int, double*, int, double*, double*, double*, double*, int);
 template void hetrd_upper<cplx>(Ctx&, hipStream_t, int, cplx*, int, double*, double*, cplx*, cplx*, int);
+template <class T> const void* hemv_scratch_touch(Ctx& c, int N, const void** all6) {
+    TrdScratch<T> sc = trd_scratch<T>(c, N);
+    if (all6) {
+        all6[0] = sc.xbuf; all6[1] = sc.P; all6[2] = sc.S; all6[3] = sc.Zp; all6[4] = sc.NP; all6[5] = sc.alphaSlot;
+    }
+    return sc.P;
+}
+template const void* hemv_scratch_touch<double>(Ctx&, int, const void**);
+template const void* hemv_scratch_touch<cplx>(Ctx&, int, const void**);
 template void hetrd_mv_sweep<double>(Ctx&, hipStream_t, int, double*, int, double*, int, double*, double*, long*, double*);
 template void hetrd_mv_sweep<cplx>(Ctx&, hipStream_t, int, cplx*, int, cplx*, int, double*, cplx*, long*, double*);
 template void hemv_upper<double>(Ctx&, hipStream_t, int, const double*, int, const double*, double*, bool);

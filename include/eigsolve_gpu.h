@@ -39,9 +39,14 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag"};
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap"};
  * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
- * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  Returns 0 / -1 (unknown name). */
+ * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
+ * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
+ * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
+ * "overlap": 1 = independent launch chains of one solve run on two streams (second half of potrf with the
+ * first half of gst; larft T factors with the tridiagonal eigensolver): -3 % latency for an isolated solve, but
+ * -15 % throughput when several solves are in flight on the GPU; 0 (default) = single stream.  Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 
 /* nvtxStartRange / nvtxEndRange (lib_eigsolve/toolbox.F90:71-97) -> roctx ranges when
