@@ -118,7 +118,10 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
     T zs = Tr<T>::zero(), Ssum = Tr<T>::zero();
     T wi_w = Tr<T>::zero(), wi_v = Tr<T>::zero(), wi_p = Tr<T>::zero();
     T vv[RU], wv[RU], pp[RP];
-    T vr = Tr<T>::zero(), acur = Tr<T>::zero();
+    T vr = Tr<T>::zero(), acur = Tr<T>::zero(), vic = Tr<T>::zero();
+    if (do_finish && do_update && wave == 0) vic = a.A[(size_t)i + (size_t)c * a.lda];   // needed in phase 2: issue now
+    T tau_early = Tr<T>::zero();
+    if (do_finish && tid == 0) tau_early = a.tau[c - 1];
 #pragma unroll
     for (int u = 0; u < RU; ++u) { vv[u] = Tr<T>::zero(); wv[u] = Tr<T>::zero(); }
 #pragma unroll
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
         }
         Ssum = wave_sum(Ssum);
         if (lane == 0) s4[wave] = Ssum;
-        if (tid == 0) sc_tau = a.tau[c - 1];
+        if (tid == 0) sc_tau = tau_early;
         __syncthreads();
         // ---------------- phase 2: alpha, w_i ----------------
         if (wave == 0) {
@@ -214,7 +217,6 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
                 T alpha = (-0.5 * abs2_(tau)) * conj_(S - Tr<T>::make(2.0 * zz, 0.0));
                 sc_alpha = alpha;
                 if (do_update) {
-                    T vic = a.A[(size_t)i + (size_t)c * a.lda];
                     T wi = tau * u + alpha * vic;
                     rowW[npo] = conj_(wi);
                     rowV[npo] = conj_(vic);
@@ -345,6 +347,8 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
     };
 
     // ---------------- issue the first batch of loads ----------------
+    T alpha_early = Tr<T>::zero();
+    if (!plain && wave == 0) alpha_early = *a.alphaSlot;   // consumed by the scalar prologue: issue with everything else
     const int nt = (n + HT - 1) / HT;
     const int ntiles = nt * (nt + 1) / 2;
     __shared__ T xcs[2][HT];   // raw column entries of v for the current / next tile
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
             if (lane == 0) {
                 double beta;
                 T tau, scale;
-                larfg_scalars<T>(ss, *a.alphaSlot, beta, tau, scale);
+                larfg_scalars<T>(ss, alpha_early, beta, tau, scale);
                 sc_scale = scale;
                 if (blockIdx.x == 0) {
                     a.e[i - 1] = beta;

@@ -505,3 +505,25 @@ def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
     assert np.abs(w - wl).max() <= 50 * n * EPS * nrm
     assert np.abs(A @ Z - Z * w[il - 1:iu]).max() <= 50 * n * EPS * nrm
     assert np.abs(Z.conj().T @ Z - np.eye(m)).max() <= 50 * n * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("opt", ["graph", "overlap"])
+def test_optional_execution_modes_are_bit_identical(env, cplx, opt):
+    """hipGraph replay of the tridiagonalization and the two-stream overlap only change HOW the same
+    kernels are issued, so results must be bit-identical to the default single-stream eager path."""
+    torch, oracle, api = env
+    n, m = 330, 80
+    A = oracle.gen_spd_fast(n, 4000 + n, cplx)
+    B = oracle.gen_spd_fast(n, 5000 + n, cplx, shift=float(n))
+    out = {}
+    try:
+        for mode in (0, 1, 1):   # second "1" replays a cached graph
+            assert api.set_option(opt, mode) == 0
+            info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
+            assert info == 0
+            out.setdefault(mode, []).append((w, Z))
+    finally:
+        api.set_option(opt, 0)
+    for w, Z in out[1]:
+        assert np.array_equal(out[0][0][0], w) and np.array_equal(out[0][0][1], Z)
