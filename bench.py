@@ -72,7 +72,8 @@ def main():
     ap.add_argument("--real", action="store_true", help="dsygvdx instead of zhegvdx")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=0, help="order of the CPU baseline sample (default: min(n, 2048))")
+    ap.add_argument("--cpu-n", type=int, default=0, help="order of the CPU baseline sample (default: min(n, 4096): "
+                    "the full C3 problem, one timed LAPACK call, about 20 s on the GPU box's host)")
     ap.add_argument("--batch", type=int, default=2,
                     help="independent problems per GPU per step (QE k-point style batch); solved by min(batch, --inflight) "
                          "host threads, each with its own context/stream")
@@ -282,7 +283,7 @@ def main():
     # ---- CPU baseline (rank 0 only, bounded sample) --------------------------------------------------
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         import scipy.linalg as sl
-        cn = args.cpu_n or min(n, 2048)
+        cn = args.cpu_n or min(n, 4096)
         cm = max(1, cn * m // n)
         Ac, Bc = gen_pair(cn, cplx, 4242, dev)
         Ah_np = Ac.T.cpu().numpy()
