@@ -976,8 +976,60 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
     hegst_rec(c, st, n2, k0 + n1, A, lda, U, ldu);
 }
 
+template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
+
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
-    hegst_rec(c, st, N, 0, A, lda, U, ldu);
+    // EIGSOLVE_GST: 0 = symmetric recursion (N^3 flops, ~16N/64 small launches), 1 = two full solves (2N^3 flops,
+    // ~4N/64 large launches), default: two solves from N = 256 up (C3: 28.3 -> 14.4 ms).
+    static const int mode = getenv("EIGSOLVE_GST") ? atoi(getenv("EIGSOLVE_GST")) : -1;
+    const bool two = mode < 0 ? (N >= 256) : (mode == 1);
+    if (two) hegst_two_solves(c, st, N, A, lda, U, ldu);
+    else hegst_rec(c, st, N, 0, A, lda, U, ldu);
+}
+
+// ---- hegst as two full triangular solves ------------------------------------------------------------
+// F = Herm(A) (completed copy), F <- U^-H F, F <- F U^-1, upper(A) <- upper(F).  2x the flops of the
+// symmetric algorithm (zhegst_gpu.F90:51-107) but ~4N/64 large launches instead of ~16N/64 small ones:
+// on MI355X the small-launch chain, not the flops, dominates the symmetric form.
+template <class T> __global__ void __launch_bounds__(256) herm_complete_kernel(int n, const T* A, int lda, T* F, int ldf) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x, by = blockIdx.y;   // tile (bx = row block, by = col block), only bx <= by launched work
+    if (bx > by) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int q = ty; q < 32; q += 8) {
+        int r = bx * 32 + tx, cc = by * 32 + q;
+        T v = Tr<T>::zero();
+        if (r < n && cc < n && r <= cc) v = A[(size_t)r + (size_t)cc * lda];
+        if (r == cc) v = Tr<T>::realpart(v);
+        tile[q][tx] = v;
+        if (r < n && cc < n && r <= cc) F[(size_t)r + (size_t)cc * ldf] = v;
+    }
+    __syncthreads();
+    // mirrored block: F(c, r) = conj(A(r, c)) for r < c
+    for (int q = ty; q < 32; q += 8) {
+        int cc = by * 32 + tx, r = bx * 32 + q;     // write F(cc, r): consecutive tx -> consecutive rows cc
+        if (r < n && cc < n && r < cc) F[(size_t)cc + (size_t)r * ldf] = conj_(tile[tx][q]);
+    }
+}
+template <class T> __global__ void __launch_bounds__(256) copy_upper_kernel(int n, const T* F, int ldf, T* A, int lda) {
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * n) return;
+    int r = (int)(id % n), cc = (int)(id / n);
+    if (r > cc) return;
+    T v = F[(size_t)r + (size_t)cc * ldf];
+    if (r == cc) v = Tr<T>::realpart(v);
+    A[(size_t)r + (size_t)cc * lda] = v;
+}
+template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+    if (N <= 0) return;
+    T* F = c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", (size_t)N * N);
+    const int nb32 = (N + 31) / 32;
+    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)A, lda, F, N);
+    trsm_LUC(c, st, N, N, U, ldu, 0, F, N);   // F <- U^-H F
+    trsm_RUN(c, st, N, N, U, ldu, 0, F, N);   // F <- F U^-1
+    size_t tot = (size_t)N * N;
+    hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, A, lda);
+    EIG_HIP(hipGetLastError());
 }
 
 template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {

@@ -510,8 +510,9 @@ def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("opt", ["graph", "overlap"])
 def test_optional_execution_modes_are_bit_identical(env, cplx, opt):
-    """hipGraph replay of the tridiagonalization and the two-stream overlap only change HOW the same
-    kernels are issued, so results must be bit-identical to the default single-stream eager path."""
+    """hipGraph replay only changes HOW the same kernels are issued: bit-identical to the eager path.  The
+    two-stream overlap uses the symmetric hegst recursion (default: two full solves): equal to rounding, and
+    itself bit-reproducible."""
     torch, oracle, api = env
     n, m = 330, 80
     A = oracle.gen_spd_fast(n, 4000 + n, cplx)
@@ -526,4 +527,9 @@ def test_optional_execution_modes_are_bit_identical(env, cplx, opt):
     finally:
         api.set_option(opt, 0)
     for w, Z in out[1]:
-        assert np.array_equal(out[0][0][0], w) and np.array_equal(out[0][0][1], Z)
+        if opt == "graph":
+            assert np.array_equal(out[0][0][0], w) and np.array_equal(out[0][0][1], Z)
+        else:   # the overlapped path pipelines the symmetric hegst recursion, the default uses two full solves
+            assert oracle.compare_1d(out[0][0][0], w)[0] <= 1e-13
+            assert oracle.compare_abs2d(out[0][0][1], Z)[0] <= 1e-9
+    assert np.array_equal(out[1][0][0], out[1][1][0]) and np.array_equal(out[1][0][1], out[1][1][1])
