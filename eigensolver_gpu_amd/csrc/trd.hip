@@ -25,6 +25,9 @@
 
 namespace eig {
 
+#ifndef EIG_MV_PREFETCH
+#define EIG_MV_PREFETCH 1
+#endif
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
 constexpr int NBMAX = 64;  // maximum panel width
@@ -466,7 +469,9 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
         if (tid < 64) { vI = vfix(xraw(r0 + tid), r0 + tid, scale); vJ = vfix(xcs[buf][tid], c0 + tid, scale); }
         const int Ic = I, Jc = J;
         t += a.gh;
+#if EIG_MV_PREFETCH
         if (t < ntiles) load_tile(buf ^ 1);   // next tile's loads fly while the barriers drain
+#endif
         __syncthreads();
         if (tid < 64) {
             T yv = (redy[0][tid] + redy[1][tid]) + (redy[2][tid] + redy[3][tid]);
@@ -484,6 +489,9 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
             }
         }
         buf ^= 1;
+#if !EIG_MV_PREFETCH
+        if (t < ntiles) load_tile(buf);
+#endif
         __syncthreads();
     }
     if (wave == 0) {
