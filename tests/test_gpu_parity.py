@@ -533,3 +533,44 @@ def test_optional_execution_modes_are_bit_identical(env, cplx, opt):
             assert oracle.compare_1d(out[0][0][0], w)[0] <= 1e-13
             assert oracle.compare_abs2d(out[0][0][1], Z)[0] <= 1e-9
     assert np.array_equal(out[1][0][0], out[1][1][0]) and np.array_equal(out[1][0][1], out[1][1][1])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,m", [(70, 20), (300, 77)])
+def test_leading_dimensions_larger_than_n(env, cplx, n, m):
+    """lda, ldb, ldz, ldz_h all different and > N (the reference takes them as separate arguments,
+    zhegvdx_gpu.F90:75-76); padding rows are poisoned and must come back untouched."""
+    torch, oracle, api = env
+    lda, ldb, ldz, ldzh = n + 3, n + 8, n + 5, n + 2
+    A = oracle.gen_spd(n, 6000 + n, cplx) if n < 100 else oracle.gen_spd_fast(n, 6000 + n, cplx)
+    B = oracle.gen_spd(n, 7000 + n, cplx, shift=float(n)) if n < 100 else oracle.gen_spd_fast(n, 7000 + n, cplx, shift=float(n))
+    dt = torch.complex128 if cplx else torch.float64
+
+    def padded(M, ld):
+        P = np.full((ld, n), 123.25, dtype=M.dtype, order="F")
+        P[:n, :] = np.triu(M)
+        P[:n, :][np.tril_indices(n, -1)] = -7.5          # strict lower part: must be preserved
+        return api.to_device(P)                          # torch (n, ld)
+
+    Ad, Bd = padded(A, lda), padded(B, ldb)
+    ws = api.Workspace(n, cplx)
+    Zd = torch.full((n, ldz), 9.0, dtype=dt, device="cuda")
+    Zh = torch.full((n, ldzh), 5.0, dtype=dt).pin_memory()
+    if cplx:
+        info = api.zhegvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.rwork, ws.lrwork, ws.work_h,
+                               ws.lwork_h, ws.rwork_h, ws.lrwork_h, ws.iwork_h, ws.liwork_h, Zh, ldzh, ws.w_h)
+    else:
+        info = api.dsygvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.work_h, ws.lwork_h, ws.iwork_h,
+                               ws.liwork_h, Zh, ldzh, ws.w_h)
+    assert info == 0
+    w = ws.w_h.numpy().copy()
+    Zhost = Zh.numpy().T            # (ldzh, n)
+    Z = np.asfortranarray(Zhost[:n, :m])
+    assert oracle.residual(A, B, w, Z) <= n * EPS
+    assert np.array_equal(api.to_host(Zd)[:n, :m], Z)
+    # padding rows untouched everywhere, strict lower(A) preserved, B holds U
+    assert np.all(api.to_host(Ad)[n:, :] == 123.25) and np.all(api.to_host(Bd)[n:, :] == 123.25)
+    assert np.all(api.to_host(Zd)[n:, :] == 9.0) and np.all(Zhost[n:, :] == 5.0)
+    assert np.all(api.to_host(Ad)[:n, :][np.tril_indices(n, -1)] == -7.5)
+    Uo, _ = oracle.potrf_upper(B)
+    assert rel(np.triu(api.to_host(Bd)[:n, :]), np.triu(Uo)) <= 100 * n * EPS
