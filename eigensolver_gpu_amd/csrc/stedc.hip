@@ -2,8 +2,8 @@
 //
 // SURVEY.md 8(f) row 1 ("next" row): replaces the host LAPACK zstedc/dstedc('I') call of the
 // reference (zheevd_gpu.F90:101, dsyevd_gpu.F90:99), which is 70 % of the wall time at N=4096 once
-// the rest of the path runs on MI355X.  Selected with eigsolve_set_option("tridiag", 1) /
-// EIGSOLVE_TRIDIAG=device; the host dstedc path stays available (north_star default).
+// the rest of the path runs on MI355X.  Default; eigsolve_set_option("tridiag", 0) / EIGSOLVE_TRIDIAG=host
+// selects the reference's host dstedc path.
 //
 // Algorithm: Cuppen's divide & conquer as organised in LAPACK dstedc/dlaed0-4 (published
 // algorithm, restated): leaves by implicit QL, then a binary tree of rank-one merges
@@ -14,7 +14,8 @@
 //   * the only sequential piece -- the deflation scan, O(n) per merge -- runs on the host between two
 //     small transfers (z and D down, index lists up);
 //   * secular roots: one wave64 per root, poles/weights staged in LDS, origin shifted to the nearest
-//     pole (delta_i = (d_i - d_K) - tau), safeguarded two-pole rational iteration + bisection;
+//     pole (delta_i = (d_i - d_K) - tau), value-and-slope matching rational iteration (~5 iterations per
+//     root) safeguarded by bisection, divisions by v_rcp_f64 + two Newton steps;
 //   * eigenvector update Q <- Q_sel * S on the fp64 MFMA engine (two gemms per merge exploiting the
 //     block structure, as dlaed3 does).
 #include <algorithm>
@@ -192,69 +193,83 @@ __global__ void __launch_bounds__(256) dc_secular_kernel(const MergeDesc* md, co
     auto W2 = [&](int i) -> double { if (use_lds) return sw2[i]; double w = wv[i]; return w * w; };
     const double rho = m.rho;
     const double EPSD = 2.220446049250313e-16;
+    // 1/x to ~1 ulp: v_rcp_f64 (about 27 bits) + two Newton steps; the IEEE division sequence is ~4x longer
+    auto frcp = [](double x) -> double {
+        double r = __builtin_amdgcn_rcp(x);
+        r = fma(fma(-x, r, 1.0), r, r);
+        r = fma(fma(-x, r, 1.0), r, r);
+        return r;
+    };
     for (int rr = 0; rr < ROOTS_PER_WAVE; ++rr) {
         const int j = first + wave * ROOTS_PER_WAVE + rr;
         if (j >= k) break;
-        int K, p1, p2;
+        int K;
         double lo, hi;
         if (j < k - 1) {
             double dj = DL(j);
             double half = 0.5 * (DL(j + 1) - dj);
             double acc = 0.0;
-            for (int i = lane; i < k; i += 64) acc += W2(i) / ((DL(i) - dj) - half);
+            for (int i = lane; i < k; i += 64) acc += W2(i) * frcp((DL(i) - dj) - half);
             double fmid = 1.0 + rho * wsum(acc);
             if (fmid > 0.0) { K = j; lo = 0.0; hi = half; }
             else { K = j + 1; lo = -half; hi = 0.0; }
-            p1 = j; p2 = j + 1;
         } else {
             double acc = 0.0;
             for (int i = lane; i < k; i += 64) acc += W2(i);
             K = k - 1; lo = 0.0; hi = rho * wsum(acc);
-            p1 = (k > 1) ? k - 2 : k - 1; p2 = k - 1;
         }
         const double dK = DL(K);
-        const double D1 = DL(p1) - dK, D2 = DL(p2) - dK;
-        const double a1 = rho * W2(p1), a2 = rho * W2(p2);
+        const double Dj = DL(j) - dK;
+        const double Dj1 = (j < k - 1) ? DL(j + 1) - dK : 0.0;
         double tau = 0.5 * (lo + hi);
-        double width_prev = 2.0 * (hi - lo);
-        for (int it = 0; it < 400; ++it) {
-            double acc = 0.0, acca = 0.0;
+        // psi (poles <= j) and phi (poles > j) are each replaced by a + b/(pole - t) matching value and slope at the
+        // current point (Bunch-Nielsen-Sorensen / Li rational model, quadratically convergent: ~5 iterations instead of
+        // ~40 for a fixed-remainder model); the quadratic is solved for the root inside the bracket, bisection safeguards.
+        for (int it = 0; it < 100; ++it) {
+            double s1l = 0.0, s2l = 0.0, s1r = 0.0, s2r = 0.0;
             for (int i = lane; i < k; i += 64) {
-                double t = W2(i) / ((DL(i) - dK) - tau);
-                acc += t; acca += fabs(t);
+                double r = frcp((DL(i) - dK) - tau);
+                double t1 = W2(i) * r, t2 = t1 * r;
+                if (i <= j) { s1l += t1; s2l += t2; } else { s1r += t1; s2r += t2; }
             }
-            acc = wsum(acc); acca = wsum(acca);
-            double g = 1.0 + rho * acc;
-            double err = 8.0 * EPSD * (1.0 + rho * acca) + EPSD * fabs(g);
+            const double psi = rho * wsum(s1l), dpsi = rho * wsum(s2l), phi = rho * wsum(s1r), dphi = rho * wsum(s2r);
+            const double g = 1.0 + psi + phi;
+            const double err = 8.0 * EPSD * (1.0 + fabs(psi) + fabs(phi)) + EPSD * fabs(g);
             if (fabs(g) <= err) break;
             if (g > 0.0) hi = tau; else lo = tau;
-            double width = hi - lo;
-            bool force_bisect = width > 0.5 * width_prev;
-            width_prev = width;
             double nw = 0.5 * (lo + hi);
-            if (!force_bisect && p1 != p2) {
-                double d1 = D1 - tau, d2 = D2 - tau;
-                double C = g - a1 / d1 - a2 / d2;
-                double A = C, B = -(C * (D1 + D2) + a1 + a2), Cc = C * D1 * D2 + a1 * D2 + a2 * D1;
-                double c1 = nw, c2 = nw;
-                bool h1 = false, h2 = false;
-                if (A == 0.0) {
-                    if (B != 0.0) { c1 = -Cc / B; h1 = true; }
+            if (it < 40) {
+                const double dj = Dj - tau;
+                const double bpsi = dpsi * dj * dj, apsi = psi - dpsi * dj;
+                if (j < k - 1) {
+                    const double dj1 = Dj1 - tau;
+                    const double bphi = dphi * dj1 * dj1, aphi = phi - dphi * dj1;
+                    const double c = 1.0 + apsi + aphi;
+                    const double A = c, B = -(c * (Dj + Dj1) + bpsi + bphi), Cq = c * Dj * Dj1 + bpsi * Dj1 + bphi * Dj;
+                    double c1 = nw, c2 = nw;
+                    bool h1 = false, h2 = false;
+                    if (A == 0.0) {
+                        if (B != 0.0) { c1 = -Cq / B; h1 = true; }
+                    } else {
+                        double disc = B * B - 4.0 * A * Cq;
+                        if (disc >= 0.0) {
+                            double q = -0.5 * (B + copysign(sqrt(disc), B));
+                            c1 = q / A; h1 = true;
+                            if (q != 0.0) { c2 = Cq / q; h2 = true; }
+                        }
+                    }
+                    if (h1 && c1 > lo && c1 < hi) nw = c1;
+                    else if (h2 && c2 > lo && c2 < hi) nw = c2;
                 } else {
-                    double disc = B * B - 4.0 * A * Cc;
-                    if (disc >= 0.0) {
-                        double q = -0.5 * (B + copysign(sqrt(disc), B));
-                        c1 = q / A; h1 = true;
-                        if (q != 0.0) { c2 = Cc / q; h2 = true; }
+                    const double c = 1.0 + apsi;
+                    if (c != 0.0) {
+                        double t = Dj + bpsi / c;
+                        if (t > lo && t < hi) nw = t;
                     }
                 }
-                if (h1 && c1 > lo && c1 < hi) nw = c1;
-                else if (h2 && c2 > lo && c2 < hi) nw = c2;
             }
-            if (!(nw > lo && nw < hi) || nw == tau) {
-                nw = 0.5 * (lo + hi);
-                if (!(nw > lo && nw < hi)) break;
-            }
+            if (nw == tau) nw = 0.5 * (lo + hi);
+            if (!(nw > lo && nw < hi)) break;
             tau = nw;
         }
         double* Sc = S + (size_t)m.off + (size_t)(m.off + j) * lds_;

@@ -14,9 +14,15 @@ import numpy as np
 EPS = np.finfo(float).eps
 
 
+ITERS = []
+
+
 def secular_root(j, d, w2, rho):
     """Root j of 1 + rho*sum(w2/(d - lam)) in (d[j], d[j+1]) (last: (d[k-1], d[k-1]+rho*sum(w2))).
-    Returns (K, tau): lam = d[K] + tau, and delta = (d - d[K]) - tau is what callers must use."""
+    Returns (K, tau): lam = d[K] + tau, and delta = (d - d[K]) - tau is what callers must use.
+    Iteration: psi (poles <= j) and phi (poles > j) are each replaced by a + b/(pole - t) matching value and
+    slope at the current point (Bunch-Nielsen-Sorensen / Li rational model, quadratically convergent), the
+    resulting quadratic is solved for the root inside the bracket; bisection safeguards it."""
     k = len(d)
     if j < k - 1:
         gap = d[j + 1] - d[j]
@@ -27,61 +33,68 @@ def secular_root(j, d, w2, rho):
             K, lo, hi = j, 0.0, mid
         else:             # origin j+1, tau in [-mid, 0)
             K, lo, hi = j + 1, -mid, 0.0
-        p1, p2 = j, j + 1
     else:
         K = k - 1
         lo, hi = 0.0, rho * np.sum(w2)
-        p1, p2 = (k - 2, k - 1) if k > 1 else (k - 1, k - 1)
     D = d - d[K]
     tau = 0.5 * (lo + hi)
-    width_prev = 2.0 * (hi - lo)
-    for it in range(400):
+    left = np.arange(k) <= j
+    for it in range(100):
         delta = D - tau
-        terms = w2 / delta
-        g = 1.0 + rho * np.sum(terms)
-        err = 8.0 * EPS * (1.0 + rho * np.sum(np.abs(terms))) + EPS * abs(g)
+        t1 = w2 / delta
+        t2 = t1 / delta
+        psi, dpsi = rho * np.sum(t1[left]), rho * np.sum(t2[left])
+        phi, dphi = rho * np.sum(t1[~left]), rho * np.sum(t2[~left])
+        g = 1.0 + psi + phi
+        err = 8.0 * EPS * (1.0 + abs(psi) + abs(phi)) + EPS * abs(g)
         if abs(g) <= err:
             break
         if g > 0:
             hi = tau
         else:
             lo = tau
-        width = hi - lo
-        force_bisect = width > 0.5 * width_prev   # the model step did not halve the bracket
-        width_prev = width
-        # two-pole model: g ~ C + rho*w2[p1]/(D[p1]-t) + rho*w2[p2]/(D[p2]-t)
-        if p1 != p2:
-            a1, a2 = rho * w2[p1], rho * w2[p2]
-            C = g - a1 / delta[p1] - a2 / delta[p2]
-            # C (D1-t)(D2-t) + a1 (D2-t) + a2 (D1-t) = 0
-            A = C
-            B = -(C * (D[p1] + D[p2]) + a1 + a2)
-            Cc = C * D[p1] * D[p2] + a1 * D[p2] + a2 * D[p1]
-            cand = None
-            if A == 0:
-                if B != 0:
-                    cand = [-Cc / B]
-            else:
-                disc = B * B - 4 * A * Cc
-                if disc >= 0:
-                    sq = np.sqrt(disc)
-                    q = -0.5 * (B + np.copysign(sq, B))
-                    cand = [q / A] + ([Cc / q] if q != 0 else [])
-            new = None
-            if cand:
-                for t in cand:
+        new = None
+        if it < 40:
+            dj = delta[j]
+            bpsi = dpsi * dj * dj
+            apsi = psi - dpsi * dj
+            if j < k - 1:
+                dj1 = delta[j + 1]
+                bphi = dphi * dj1 * dj1
+                aphi = phi - dphi * dj1
+                c = 1.0 + apsi + aphi
+                Dj, Dj1 = D[j], D[j + 1]
+                # c (Dj - t)(Dj1 - t) + bpsi (Dj1 - t) + bphi (Dj - t) = 0
+                A = c
+                Bq = -(c * (Dj + Dj1) + bpsi + bphi)
+                Cq = c * Dj * Dj1 + bpsi * Dj1 + bphi * Dj
+                cands = []
+                if A == 0:
+                    if Bq != 0:
+                        cands = [-Cq / Bq]
+                else:
+                    disc = Bq * Bq - 4 * A * Cq
+                    if disc >= 0:
+                        q = -0.5 * (Bq + np.copysign(np.sqrt(disc), Bq))
+                        cands = [q / A] + ([Cq / q] if q != 0 else [])
+                for t in cands:
                     if lo < t < hi:
                         new = t
                         break
-        else:
-            new = None
-        if new is None or force_bisect:
-            new = 0.5 * (lo + hi)
-        if not (lo < new < hi) or new == tau:
+            else:
+                c = 1.0 + apsi
+                if c != 0:
+                    t = D[j] + bpsi / (-c) if False else D[j] - bpsi / c
+                    # c + bpsi/(Dj - t) = 0  ->  t = Dj + bpsi/c
+                    t = D[j] + bpsi / c
+                    if lo < t < hi:
+                        new = t
+        if new is None or new == tau:
             new = 0.5 * (lo + hi)
             if not (lo < new < hi):
                 break
         tau = new
+    ITERS.append(it + 1)
     return K, tau
 
 
@@ -203,3 +216,5 @@ if __name__ == "__main__":
     check(rng.standard_normal(n), e0, "zeros in e")
     check(10.0 ** (-np.arange(n) / 10.0), 10.0 ** (-np.arange(n - 1) / 10.0) * 0.5, "graded")
     check(rng.standard_normal(n) * 1e150, rng.standard_normal(n - 1) * 1e150, "huge scale")
+    it = np.array(ITERS)
+    print("secular iterations: mean %.1f median %d p99 %d max %d over %d roots" % (it.mean(), np.median(it), np.percentile(it, 99), it.max(), len(it)))
