@@ -51,6 +51,11 @@ __host__ __device__ inline void fmac_(cplx& a, cplx b, cplx c) {
     a.y = fma(b.x, c.y, a.y); a.y = fma(-b.y, c.x, a.y);
 }
 
+// c ? a : b as scalar selects.  A ternary on the struct type becomes control flow and LLVM then sinks a
+// preceding load into the taken branch -- a conditional load with its own wait; this keeps loads unconditional.
+__host__ __device__ inline double sel(bool c, double a, double b) { return c ? a : b; }
+__host__ __device__ inline cplx sel(bool c, cplx a, cplx b) { return cplx{c ? a.x : b.x, c ? a.y : b.y}; }
+
 template <class T> struct Tr;
 template <> struct Tr<double> {
     static constexpr bool cx = false;

@@ -1,0 +1,121 @@
+// lanes.h -- wave64 cross-lane primitives for gfx950 (internal).
+//
+// __shfl_xor lowers to ds_bpermute_b32: every dependent step is an LDS-crossbar round trip (>100 cycles),
+// and the panel kernels of the tridiagonalization sit on chains of 6-12 such steps per launch.  These
+// helpers use what the hardware offers instead:
+//   * DPP row operations (quad_perm, row_ror, row_half_mirror, row_mirror): a VALU move, a few cycles;
+//   * v_readlane for the last two levels of a full-wave sum;
+//   * v_permlane32_swap / v_permlane16_swap (new in gfx950): exchange halves / odd-even rows of two
+//     registers in one instruction -- exactly one level of a transpose-reduce butterfly.
+#pragma once
+#include "common.h"
+
+namespace eig {
+
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_ROR8 = 0x128;        // row_ror:8  == lane ^ 8 inside a 16-lane row
+constexpr int DPP_HALF_MIRROR = 0x141; // lane -> 7 - lane inside each 8 lanes
+constexpr int DPP_MIRROR = 0x140;      // lane -> 15 - lane inside each 16-lane row
+
+// value of `v` in the lane selected by CTRL (all lanes enabled)
+template <int CTRL> __device__ __forceinline__ double dpp_get(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// lanes in the banks of BANK_A receive a from their CTRL partner, the other lanes receive b from theirs
+template <int CTRL, int BANK_A> __device__ __forceinline__ double dpp_get2(double a, double b) {
+    int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    int lo = __builtin_amdgcn_update_dpp(0, blo, CTRL, 0xf, 0xf ^ BANK_A, false);
+    int hi = __builtin_amdgcn_update_dpp(0, bhi, CTRL, 0xf, 0xf ^ BANK_A, false);
+    lo = __builtin_amdgcn_update_dpp(lo, alo, CTRL, 0xf, BANK_A, false);
+    hi = __builtin_amdgcn_update_dpp(hi, ahi, CTRL, 0xf, BANK_A, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ cplx dpp_get(cplx v) { return cplx{dpp_get<CTRL>(v.x), dpp_get<CTRL>(v.y)}; }
+template <int CTRL, int BANK_A> __device__ __forceinline__ cplx dpp_get2(cplx a, cplx b) {
+    return cplx{dpp_get2<CTRL, BANK_A>(a.x, b.x), dpp_get2<CTRL, BANK_A>(a.y, b.y)};
+}
+
+// sum over the 16 lanes of each row, result in every lane of the row
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_get<DPP_XOR1>(v);
+    v += dpp_get<DPP_XOR2>(v);
+    v += dpp_get<DPP_HALF_MIRROR>(v);
+    v += dpp_get<DPP_MIRROR>(v);
+    return v;
+}
+__device__ __forceinline__ double read_lane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// sum over the 64 lanes, result (wave-uniform) in every lane.  Must be called with all 64 lanes active.
+__device__ __forceinline__ double wave_sum(double v) {
+    v = row_sum16(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+__device__ __forceinline__ cplx wave_sum(cplx v) { return cplx{wave_sum(v.x), wave_sum(v.y)}; }
+__device__ __forceinline__ cplx row_sum16(cplx v) { return cplx{row_sum16(v.x), row_sum16(v.y)}; }
+
+// a' = {lanes 0-31: a, lanes 32-63: b(lane-32)},  b' = {lanes 0-31: a(lane+32), lanes 32-63: b}
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// rows of 16 lanes: a' = {a.r0, b.r0, a.r2, b.r2},  b' = {a.r1, b.r1, a.r3, b.r3}
+__device__ __forceinline__ void swap_rows(double& a, double& b) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap_halves(cplx& a, cplx& b) { swap_halves(a.x, b.x); swap_halves(a.y, b.y); }
+__device__ __forceinline__ void swap_rows(cplx& a, cplx& b) { swap_rows(a.x, b.x); swap_rows(a.y, b.y); }
+
+// 16 per-lane partials t[0..15] (one per column) -> the full 64-lane sum of column (lane>>2)&15 in every
+// lane of the quad.  Levels: halves (permlane32_swap), rows (permlane16_swap), 8 (row_ror:8), 4 (half
+// mirror), then the quad sum.  Deterministic summation order.
+template <class T> __device__ __forceinline__ T transpose_reduce16(T (&t)[16], int lane) {
+    T u8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        T x = t[j], y = t[j + 8];
+        swap_halves(x, y);
+        u8[j] = x + y;            // lanes 0-31: column j, lanes 32-63: column j+8
+    }
+    T u4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        T x = u8[j], y = u8[j + 4];
+        swap_rows(x, y);
+        u4[j] = x + y;            // + 4 * (bit 4 of lane)
+    }
+    const bool b3 = lane & 8, b2 = lane & 4;
+    T u2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        T x = u4[j], y = u4[j + 2];
+        T recv = dpp_get2<DPP_ROR8, 0x3>(x, y);       // banks 0,1 (bit 3 clear) keep x and receive x
+        u2[j] = (b3 ? y : x) + recv;
+    }
+    T recv = dpp_get2<DPP_HALF_MIRROR, 0x5>(u2[0], u2[1]);   // banks 0,2 (bit 2 clear)
+    T out = (b2 ? u2[1] : u2[0]) + recv;
+    out = out + dpp_get<DPP_XOR2>(out);
+    out = out + dpp_get<DPP_XOR1>(out);
+    return out;
+}
+
+// 1/x to ~1 ulp without the IEEE division sequence (x normal, nonzero): v_rcp_f64 + two Newton steps
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+}  // namespace eig

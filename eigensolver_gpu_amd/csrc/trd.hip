@@ -22,11 +22,22 @@
 //         w^H v = conj(tau) * conj( v^H A v - 2 Re(z1^H z2) ),
 //     and v^H A v is accumulated tile by tile inside the mat-vec.
 #include "trd.h"
+#include "lanes.h"
 
 namespace eig {
 
 #ifndef EIG_MV_PREFETCH
 #define EIG_MV_PREFETCH 1
+#endif
+#ifndef EIG_TRD_TIMING
+#define EIG_TRD_TIMING 0
+#endif
+#if EIG_TRD_TIMING
+__device__ unsigned long long g_trd_stamp[2][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
+__device__ unsigned long long g_trd_count[2];
+#define TSTAMP(KID, PH, T0) do { if (blockIdx.x == (KID == 0 ? gg : 0) && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
+#else
+#define TSTAMP(KID, PH, T0) do { } while (0)
 #endif
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
@@ -41,26 +52,19 @@ template <class T> struct PanelArgs {
     T* P; int ldp;     // hemv partials P[q*ldp + row]
     T* S;              // per-hemv-workgroup partial of v^H A v
     T* Zp;             // gemv partials Zp[(chunk*2 + which)*NBMAX + kk]
-    double* NP;        // per-row-workgroup partial of the squared norm
+    double* NP;        // per-wave (4 rows) partials of the squared norm
     T* alphaSlot;      // A(i-1,i) after the update
-    int nblkA;         // row-kernel workgroups that produced NP for column i
+    int nblkA;         // norm partials (one per row-kernel wave) produced for column i
     int gh;            // hemv workgroups used for the column being finished / generated
     int nchunk;        // gemv row chunks for that column
     int ablate;        // debug/timing only (EIGSOLVE_ABLATE): skips parts of the row kernel, results invalid
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ cplx wave_sum(cplx v) { return cplx{wave_sum(v.x), wave_sum(v.y)}; }
-__device__ __forceinline__ double shx(double v, int o) { return __shfl_xor(v, o); }
-__device__ __forceinline__ cplx shx(cplx v, int o) { return cplx{__shfl_xor(v.x, o), __shfl_xor(v.y, o)}; }
-
-// larfg scalars exactly as the reference computes them (zhetrd_gpu.F90:275-311): scaling by
-// max(|ar|,|ai|,xnorm), no safe-minimum loop.  Degenerate case follows LAPACK (tau=0, beta=ar).
-template <class T> __device__ void larfg_scalars(double ss, T alpha, double& beta, T& tau, T& scale) {
+// larfg scalars with the reference's scaling (zhetrd_gpu.F90:275-311: scale by max(|ar|,|ai|,xnorm), no
+// safe-minimum loop).  Degenerate case follows LAPACK (tau=0, beta=ar).  This sits on the critical path of
+// every column (all lanes of a wave evaluate it redundantly), so the three quotients are multiplications by
+// Newton-refined reciprocals instead of IEEE division sequences.
+template <class T> __device__ __forceinline__ void larfg_scalars(double ss, T alpha, double& beta, T& tau, T& scale) {
     double ar = real_(alpha), ai = imag_(alpha);
     if (ss == 0.0 && ai == 0.0) {
         beta = ar;
@@ -71,212 +75,210 @@ template <class T> __device__ void larfg_scalars(double ss, T alpha, double& bet
     double xnorm = sqrt(ss);
     double rv1 = fabs(ar), rv2 = fabs(ai);
     double scal = fmax(fmax(rv1, rv2), xnorm);
-    double inv = 1.0 / scal;
+    double inv = fast_rcp(scal);
     rv1 *= inv; rv2 *= inv; xnorm *= inv;
     beta = -copysign(scal * sqrt(rv1 * rv1 + rv2 * rv2 + xnorm * xnorm), ar);
-    tau = Tr<T>::make((beta - ar) / beta, -ai / beta);
+    double rb = fast_rcp(beta);
+    tau = Tr<T>::make((beta - ar) * rb, -ai * rb);
     if constexpr (Tr<T>::cx) {
-        double xr = ar - beta, xi = ai;
-        if (fabs(xi) < fabs(xr)) {
-            double q = xi / xr, d = 1.0 / (xr + xi * q);
-            scale = cplx{d, -q * d};
-        } else {
-            double q = xr / xi, d = 1.0 / (xi + xr * q);
-            scale = cplx{q * d, -d};
-        }
+        // 1/(alpha - beta) = conj(x) / |x|^2 on the scaled x (|x| in [1, 3])
+        double xr = (ar - beta) * inv, xi = ai * inv;
+        double r = fast_rcp(xr * xr + xi * xi) * inv;
+        scale = cplx{xr * r, -xi * r};
     } else {
-        scale = 1.0 / (ar - beta);
+        scale = fast_rcp(ar - beta);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// panel_row_kernel : 16 rows x 16 column-groups per workgroup.  Every global load the kernel
-// needs (gemv partials, v^H A v partials, the row-i data for w_i, this thread's slice of the V/W
-// panel and of the hemv partials) is issued before the first barrier, so the kernel costs one
-// memory round trip plus a handful of LDS reductions instead of a chain of dependent loads.
+// panel_row_kernel : 16 rows per workgroup, one matrix row per 16-lane DPP row (4 rows per wave), the 16
+// lanes of a row split the pending panel columns / hemv stripes.  Every global load the kernel needs is
+// issued up front, branch-free (clamped address + select), chain-critical ones first.  One workgroup
+// barrier (the gemv / v^H A v partial sums are gathered by the whole workgroup); after it each wave works
+// alone: alpha and w_i are evaluated redundantly per wave, the per-row sums are DPP row reductions.
+//   do_finish: finish W(:,c), c = i+1, from the hemv partials of the previous mat-vec
+//   do_update: apply the pending rank-2 updates to column i, emit xbuf / norm partials / alpha slot
 // ------------------------------------------------------------------------------------------
 constexpr int RR = 16;   // rows per workgroup
-constexpr int RG = 16;   // column groups per workgroup
-constexpr int RU = 4;    // panel columns per group (NBMAX / RG)
-constexpr int RP = 8;    // hemv stripes per group (supports N <= RP*RG*HT = 8192; larger loops)
+constexpr int RG = 16;   // lanes per row
+constexpr int RUMAX = 4; // panel columns per lane (NBMAX / RG)
+constexpr int RPMAX = 8; // hemv stripes per lane without the tail loop (N <= RPMAX*RG*HT = 8192)
+constexpr int NPW = 4;   // norm partials per workgroup (one per wave)
+constexpr int ZC = 4;    // gemv chunk partials per lane without the tail loop (256 lanes x 4 = 128 sums x 8 chunks: N <= 4096)
+constexpr int SC = 2;    // v^H A v partials per lane without the tail loop (512 hemv workgroups)
 
-template <class T>
-__global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_finish, int do_update) {
+// FIN / UPD are compile-time, and RU / RP (panel columns / hemv stripes per lane, rounded up by the host) size
+// the unconditional load groups: every load is issued, in a fixed order, so the compiler can wait for exactly
+// the values it needs (s_waitcnt vmcnt(k) with the later loads still in flight) instead of for everything.
+template <class T, bool FIN, bool UPD, int RU, int RP>
+__global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a) {
+    constexpr bool do_finish = FIN, do_update = UPD;
     const int i = a.i, c = i + 1;
     const int npo = do_finish ? a.np - 1 - c : 0;  // columns older than c inside the panel
     const int wbase = a.np - a.nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rl = tid & (RR - 1), g = tid >> 4;
-    const int r = blockIdx.x * RR + rl;
+    const int g = lane & (RG - 1), rr = lane >> 4;
+#if EIG_TRD_TIMING
+    const int gg = 0;
+    const long long T0 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trd_count[1], 1ULL);
+#endif
+    const int r = blockIdx.x * RR + wave * 4 + rr;
     const int rows = i + 1;
     const bool active = r < rows;
-    const int ntc = (c + HT - 1) / HT;  // hemv stripes of the column being finished (n = c)
+    const size_t rc = (size_t)min(r, rows - 1);   // clamped row: loads stay in bounds, results are masked
+    const int ntc = (c + HT - 1) / HT;            // hemv stripes of the column being finished (n = c)
 
-    __shared__ T z1s[NBMAX], z2s[NBMAX], rowW[NBMAX + 1], rowV[NBMAX + 1];
-    __shared__ T red2[RG][RR], red3[RG][RR];
+    __shared__ T z1s[2][NBMAX], z2s[2][NBMAX];             // two half sums each (chunks split over the wave pairs)
+    __shared__ T rowW[4][NBMAX + 1], rowV[4][NBMAX + 1];   // private to each wave
     __shared__ T s4[4];
-    __shared__ T sc_tau, sc_alpha;
 
-    // ---------------- phase 0: issue every load ----------------
-    T zs = Tr<T>::zero(), Ssum = Tr<T>::zero();
-    T wi_w = Tr<T>::zero(), wi_v = Tr<T>::zero(), wi_p = Tr<T>::zero();
-    T vv[RU], wv[RU], pp[RP];
-    T vr = Tr<T>::zero(), acur = Tr<T>::zero(), vic = Tr<T>::zero();
-    if (do_finish && do_update && wave == 0) vic = a.A[(size_t)i + (size_t)c * a.lda];   // needed in phase 2: issue now
-    T tau_early = Tr<T>::zero();
-    if (do_finish && tid == 0) tau_early = a.tau[c - 1];
-#pragma unroll
-    for (int u = 0; u < RU; ++u) { vv[u] = Tr<T>::zero(); wv[u] = Tr<T>::zero(); }
-#pragma unroll
-    for (int u = 0; u < RP; ++u) pp[u] = Tr<T>::zero();
-    if (do_finish) {
-        // independent, branch-free loads (a `for (...) s += x[q]` loop is a chain of dependent round trips)
-        if (tid < 2 * NBMAX) {
-            int which = tid >> 6, kk = tid & 63;
-            if (kk < npo) {
-                T zt[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    int ch = min(u, a.nchunk - 1);
-                    T t = a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
-                    zt[u] = (u < a.nchunk) ? t : Tr<T>::zero();
-                }
-                for (int ch = 8; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) zs = zs + zt[u];
-            }
+    // ---------------- phase 0: issue every load (raw, unconditional, clamped), chain-critical ones first -------
+    const T zero = Tr<T>::zero();
+    T tau = zero, vic = zero, l_ww = zero, l_wv = zero, l_p0 = zero, vr = zero, acur = zero;
+    T zt[ZC], st[SC], tv[RU], tw[RU], pt[RP];
+    const int kz = min(lane, max(npo - 1, 0));
+    const int zwhich = wave & 1, zhalf = wave >> 1;   // waves 0,2: z1 (A columns); 1,3: z2 (W columns)
+    if constexpr (do_finish) {
+        // (a) what alpha and w_i need, per wave
+        tau = a.tau[c - 1];
+        if constexpr (do_update) {
+            vic = a.A[(size_t)i + (size_t)c * a.lda];
+            const int kl = min(c + 1 + kz, a.np - 1);
+            l_ww = a.W[(size_t)i + (size_t)(kl - wbase) * a.ldw];
+            l_wv = a.A[(size_t)i + (size_t)kl * a.lda];
+            l_p0 = a.P[(size_t)min(lane, ntc - 1) * a.ldp + i];
         }
-        {
-            T st4[4];
+        // (b) partial sums gathered by the workgroup: stacked gemv and v^H A v
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int q = tid + 256 * u;
-                T t = a.S[min(q, a.gh - 1)];
-                st4[u] = (q < a.gh) ? t : Tr<T>::zero();
-            }
-            for (int q = tid + 1024; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
-            Ssum = Ssum + ((st4[0] + st4[1]) + (st4[2] + st4[3]));
-        }
-        if (do_update && wave == 0) {
-            if (lane < npo) {
-                int k = c + 1 + lane;
-                wi_w = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
-                wi_v = a.A[(size_t)i + (size_t)k * a.lda];
-            }
-            T p0 = a.P[(size_t)min(lane, ntc - 1) * a.ldp + i];
-            T p1 = a.P[(size_t)min(lane + 64, ntc - 1) * a.ldp + i];
-            wi_p = ((lane < ntc) ? p0 : Tr<T>::zero()) + ((lane + 64 < ntc) ? p1 : Tr<T>::zero());
-            for (int q = lane + 128; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];
-        }
-        if (active) {
+        for (int u = 0; u < ZC; ++u) zt[u] = a.Zp[(size_t)(min(zhalf * ZC + u, a.nchunk - 1) * 2 + zwhich) * NBMAX + kz];
 #pragma unroll
-            for (int u = 0; u < RU; ++u) {
-                int kk = g + RG * u;
-                if (kk < npo && !(a.ablate & 1)) {
-                    int k = c + 1 + kk;
-                    vv[u] = a.A[(size_t)r + (size_t)k * a.lda];
-                    wv[u] = a.W[(size_t)r + (size_t)(k - wbase) * a.ldw];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < RP; ++u) {
-                int q = g + RG * u;
-                if (q < ntc && !(a.ablate & 2)) pp[u] = a.P[(size_t)q * a.ldp + r];
-            }
-            for (int q = g + RG * RP; q < ntc; q += RG) pp[0] = pp[0] + a.P[(size_t)q * a.ldp + r];
-            if (g == 0) vr = a.A[(size_t)r + (size_t)c * a.lda];
-        }
-    }
-    if (do_update && active && g == 0) acur = a.A[(size_t)r + (size_t)i * a.lda];
-
-    if (do_finish) {
-        // ---------------- phase 1: gemv sums, v^H A v ----------------
-        if (tid < 2 * NBMAX) {
-            int which = tid >> 6, kk = tid & 63;
-            if (kk < npo) { if (which == 0) z1s[kk] = zs; else z2s[kk] = zs; }
-        }
-        Ssum = wave_sum(Ssum);
-        if (lane == 0) s4[wave] = Ssum;
-        if (tid == 0) sc_tau = tau_early;
-        __syncthreads();
-        // ---------------- phase 2: alpha, w_i ----------------
-        if (wave == 0) {
-            double zz = 0.0;
-            T u = wi_p;
-            if (lane < npo) {
-                T t = Tr<T>::zero();
-                fmac_(t, z1s[lane], z2s[lane]);
-                zz = real_(t);
-                u = u - (wi_w * z1s[lane] + wi_v * z2s[lane]);
-                rowW[lane] = conj_(wi_w);
-                rowV[lane] = conj_(wi_v);
-            }
-            zz = wave_sum(zz);
-            if (do_update) u = wave_sum(u);
-            if (lane == 0) {
-                T tau = sc_tau;
-                T S = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-                // alpha = -1/2 tau (w'^H v),  w'^H v = conj(tau) conj(S - 2 Re(z1^H z2))
-                T alpha = (-0.5 * abs2_(tau)) * conj_(S - Tr<T>::make(2.0 * zz, 0.0));
-                sc_alpha = alpha;
-                if (do_update) {
-                    T wi = tau * u + alpha * vic;
-                    rowW[npo] = conj_(wi);
-                    rowV[npo] = conj_(vic);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---------------- phase 3: this thread's slice ----------------
-    T acc2 = Tr<T>::zero(), acc3 = Tr<T>::zero();
-    if (do_finish && active) {
+        for (int u = 0; u < SC; ++u) st[u] = a.S[min(tid + 256 * u, a.gh - 1)];
+        // (c) this lane's slice of its row
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
-            int kk = g + RG * u;
+            const int k = min(c + 1 + min(g + RG * u, max(npo - 1, 0)), a.np - 1);
+            tv[u] = a.A[rc + (size_t)k * a.lda];
+            tw[u] = a.W[rc + (size_t)(k - wbase) * a.ldw];
+        }
+#pragma unroll
+        for (int u = 0; u < RP; ++u) pt[u] = a.P[(size_t)min(g + RG * u, ntc - 1) * a.ldp + rc];
+        vr = a.A[rc + (size_t)c * a.lda];
+    }
+    if constexpr (do_update) acur = a.A[rc + (size_t)i * a.lda];
+    __builtin_amdgcn_sched_barrier(0);
+    TSTAMP(1, 0, T0);   // loads issued
+
+    T alpha = zero;
+    if constexpr (do_finish) {
+        // ---------------- phase 1: gather the partial sums (the only workgroup barrier) ----------------
+        T zs = zero, Ssum = zero;
+#pragma unroll
+        for (int u = 0; u < ZC; ++u) zs = zs + sel(zhalf * ZC + u < a.nchunk, zt[u], zero);
+#pragma unroll
+        for (int u = 0; u < SC; ++u) Ssum = Ssum + sel(tid + 256 * u < a.gh, st[u], zero);
+        // tails beyond the unrolled counts (N > 4096 or more than 512 hemv workgroups)
+        if (zhalf == 1)
+            for (int ch = 2 * ZC; ch < a.nchunk; ++ch) zs = zs + a.Zp[(size_t)(ch * 2 + zwhich) * NBMAX + kz];
+        for (int q = tid + 256 * SC; q < a.gh; q += 256) Ssum = Ssum + a.S[q];
+        if (lane < npo) { if (zwhich == 0) z1s[zhalf][lane] = zs; else z2s[zhalf][lane] = zs; }
+        Ssum = wave_sum(Ssum);
+        if (lane == 0) s4[wave] = Ssum;
+        TSTAMP(1, 1, T0);   // critical loads arrived
+        __syncthreads();
+        TSTAMP(1, 2, T0);
+        // ---------------- phase 2: alpha and w_i, redundantly per wave ----------------
+        const T z1l = sel(lane < npo, z1s[0][kz] + z1s[1][kz], zero), z2l = sel(lane < npo, z2s[0][kz] + z2s[1][kz], zero);
+        T t = zero;
+        fmac_(t, z1l, z2l);
+        const double zz = wave_sum(real_(t));
+        const T S = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        // alpha = -1/2 tau (w'^H v),  w'^H v = conj(tau) conj(S - 2 Re(z1^H z2))
+        alpha = (-0.5 * abs2_(tau)) * conj_(S - Tr<T>::make(2.0 * zz, 0.0));
+        if constexpr (do_update) {
+            const T wi_w = sel(lane < npo, l_ww, zero), wi_v = sel(lane < npo, l_wv, zero);
+            T wi_p = sel(lane < ntc, l_p0, zero);
+            for (int q = lane + 64; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];   // N > 4096 only
+            const T u = wave_sum(wi_p - (wi_w * z1l + wi_v * z2l));
+            const T wi = tau * u + alpha * vic;
+            if (lane < npo) { rowW[wave][lane] = conj_(wi_w); rowV[wave][lane] = conj_(wi_v); }
+            if (lane == 0) { rowW[wave][npo] = conj_(wi); rowV[wave][npo] = conj_(vic); }
+            __builtin_amdgcn_wave_barrier();   // wave-private LDS: program order is enough, keep the compiler from reordering
+        }
+    }
+
+    // ---------------- phase 3: this lane's slice, then the DPP row sums ----------------
+    // (the row data -- the bulk of the loads, issued last -- is first touched here, after the scalar chain)
+    __builtin_amdgcn_sched_barrier(0);
+    T acc2 = zero, acc3 = zero;
+    if constexpr (do_finish) {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int kk = g + RG * u;
             if (kk < npo) {
-                acc2 = acc2 - (wv[u] * z1s[kk] + vv[u] * z2s[kk]);
-                if (do_update) acc3 = acc3 + (vv[u] * rowW[kk] + wv[u] * rowV[kk]);
+                const T vvu = sel(active, tv[u], zero), wvu = sel(active, tw[u], zero);
+                acc2 = acc2 - (wvu * (z1s[0][kk] + z1s[1][kk]) + vvu * (z2s[0][kk] + z2s[1][kk]));
+                if constexpr (do_update) acc3 = acc3 + (vvu * rowW[wave][kk] + wvu * rowV[wave][kk]);
             }
         }
 #pragma unroll
-        for (int u = 0; u < RP; ++u) acc2 = acc2 + pp[u];
+        for (int u = 0; u < RP; ++u) acc2 = acc2 + sel((g + RG * u < ntc) && active, pt[u], zero);
+        for (int q = g + RG * RP; q < ntc; q += RG) acc2 = acc2 + sel(active, a.P[(size_t)q * a.ldp + rc], zero);
     }
-    red2[g][rl] = acc2;
-    red3[g][rl] = acc3;
-    __syncthreads();
-    // ---------------- phase 4: one thread per row finishes ----------------
-    if (tid < RR) {
-        double contrib = 0.0;
-        if (active) {
-            T anew = acur;
-            if (do_finish) {
-                T u = Tr<T>::zero(), upd = Tr<T>::zero();
-#pragma unroll
-                for (int q = 0; q < RG; ++q) { u = u + red2[q][rl]; upd = upd + red3[q][rl]; }
-                T wr = sc_tau * u + sc_alpha * vr;
-                a.W[(size_t)r + (size_t)(c - wbase) * a.ldw] = wr;
-                if (do_update) {
-                    upd = upd + (vr * rowW[npo] + wr * rowV[npo]);
-                    anew = acur - upd;
-                    if (r == i) anew = Tr<T>::realpart(anew);
-                    a.A[(size_t)r + (size_t)i * a.lda] = anew;
-                }
-            }
-            if (do_update) {
-                a.xbuf[r] = anew;
-                if (r <= i - 2) contrib = abs2_(anew);
-                if (r == i - 1) *a.alphaSlot = anew;
-            }
-        }
-        if (do_update) {
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
-            if (tid == 0) a.NP[blockIdx.x] = contrib;
+    TSTAMP(1, 3, T0);       // row data arrived, slices done
+    const T urow = row_sum16(acc2);
+    T upd = row_sum16(acc3);
+    // ---------------- phase 4: finish the row (all 16 lanes hold the same values, lane g == 0 stores) ----------------
+    const bool writer = active && g == 0;
+    T anew = acur;
+    if constexpr (do_finish) {
+        const T wr = tau * urow + alpha * vr;
+        if (writer) a.W[(size_t)r + (size_t)(c - wbase) * a.ldw] = wr;
+        if constexpr (do_update) {
+            upd = upd + (vr * rowW[wave][npo] + wr * rowV[wave][npo]);
+            anew = acur - upd;
+            if (r == i) anew = Tr<T>::realpart(anew);
+            if (writer) a.A[(size_t)r + (size_t)i * a.lda] = anew;
         }
     }
+    TSTAMP(1, 4, T0);
+    if constexpr (do_update) {
+        if (writer) {
+            a.xbuf[r] = anew;
+            if (r == i - 1) *a.alphaSlot = anew;
+        }
+        double contrib = (writer && r <= i - 2) ? abs2_(anew) : 0.0;
+        contrib = (read_lane(contrib, 0) + read_lane(contrib, 16)) + (read_lane(contrib, 32) + read_lane(contrib, 48));
+        if (lane == 0) a.NP[blockIdx.x * NPW + wave] = contrib;
+    }
+    TSTAMP(1, 5, T0);       // end
 }
+
+// host-side choice of the load-group sizes
+template <class T, bool FIN, bool UPD>
+static void launch_row(hipStream_t st, int grid, const PanelArgs<T>& a, int npo, int ntc) {
+    const int ru = npo <= 16 ? 1 : (npo <= 32 ? 2 : (npo <= 48 ? 3 : 4));
+    const int rp = ntc <= 16 ? 1 : (ntc <= 32 ? 2 : (ntc <= 64 ? 4 : 8));
+#define EIG_ROW(RU_, RP_) hipLaunchKernelGGL((panel_row_kernel<T, FIN, UPD, RU_, RP_>), dim3(grid), dim3(256), 0, st, a)
+#define EIG_ROW_RP(RU_) do { if (rp == 1) EIG_ROW(RU_, 1); else if (rp == 2) EIG_ROW(RU_, 2); else if (rp == 4) EIG_ROW(RU_, 4); else EIG_ROW(RU_, 8); } while (0)
+    if constexpr (!FIN) { EIG_ROW(1, 1); }
+    else if constexpr (!UPD) { EIG_ROW_RP(4); }   // once per panel: only the stripe count is specialised
+    else {
+        if (ru == 1) EIG_ROW_RP(1); else if (ru == 2) EIG_ROW_RP(2); else if (ru == 3) EIG_ROW_RP(3); else EIG_ROW_RP(4);
+    }
+#undef EIG_ROW_RP
+#undef EIG_ROW
+}
+
+#if EIG_TRD_TIMING
+extern "C" int eigsolve_debug_trd_timing(unsigned long long* out18) {
+    unsigned long long st[2][16], cn[2];
+    if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_trd_stamp), sizeof st) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(cn, HIP_SYMBOL(g_trd_count), sizeof cn) != hipSuccess) return -1;
+    for (int k = 0; k < 2; ++k) { out18[k * 9] = cn[k]; for (int p = 0; p < 8; ++p) out18[k * 9 + 1 + p] = st[k][p]; }
+    return 0;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // panel_mv_kernel : larfg scalars + Hermitian mat-vec (upper, each element read once) + stacked
@@ -285,47 +287,9 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a, int do_f
 // Grid = [gemv workgroups | hemv workgroups]: the (short, latency-bound) gemv items start first
 // and hide under the bandwidth-bound tiles.  Loads are issued before the scalar prologue.
 // ------------------------------------------------------------------------------------------
-template <class T, int NCOL>
-__device__ __forceinline__ void transpose_reduce16(T (&t)[NCOL], int lane, T& out) {
-    // 16 per-lane column partials -> every 4-lane quad ends with the full 64-lane sum of column (lane>>2)&15
-    static_assert(NCOL == 16, "");
-    T u8[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bool hi = lane & 32;
-        T send = hi ? t[j] : t[j + 8];
-        T keep = hi ? t[j + 8] : t[j];
-        u8[j] = keep + shx(send, 32);
-    }
-    T u4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bool hi = lane & 16;
-        T send = hi ? u8[j] : u8[j + 4];
-        T keep = hi ? u8[j + 4] : u8[j];
-        u4[j] = keep + shx(send, 16);
-    }
-    T u2[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        bool hi = lane & 8;
-        T send = hi ? u4[j] : u4[j + 2];
-        T keep = hi ? u4[j + 2] : u4[j];
-        u2[j] = keep + shx(send, 8);
-    }
-    {
-        bool hi = lane & 4;
-        T send = hi ? u2[0] : u2[1];
-        T keep = hi ? u2[1] : u2[0];
-        out = keep + shx(send, 4);
-    }
-    out = out + shx(out, 2);
-    out = out + shx(out, 1);
-}
-
 __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
-    // t = J(J+1)/2 + I, I <= J
-    J = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    // t = J(J+1)/2 + I, I <= J.  Single-precision estimate (one v_sqrt_f32) + exact integer correction.
+    J = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
     while ((J + 1) * (J + 2) / 2 <= t) ++J;
     while (J * (J + 1) / 2 > t) --J;
     I = t - J * (J + 1) / 2;
@@ -335,169 +299,194 @@ template <class T>
 __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain, int gg) {
     const int i = a.i, n = i;  // v has n entries (rows 0..i-1), v(n-1) = 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if EIG_TRD_TIMING
+    const long long T0 = __builtin_readcyclecounter();
+    if (blockIdx.x == gg && threadIdx.x == 0) atomicAdd(&g_trd_count[0], 1ULL);
+#endif
     __shared__ T redy[4][64];
     __shared__ T redt[64];
-    __shared__ T sc_scale;
+    __shared__ T xcs[2][HT];   // xh entries of the current / next tile's columns
+    constexpr int NPL = 16;    // norm partials per lane loaded up front (N <= 4096 without the tail loop)
     const bool is_gemv = (int)blockIdx.x < gg;
     const int hb = (int)blockIdx.x - gg;  // hemv workgroup index
 
-    // raw (unscaled) entry of the column; the scale is applied after the prologue
-    auto xraw = [&](int r) -> T { return (r < n) ? a.xbuf[r] : Tr<T>::zero(); };
-    auto vfix = [&](T x, int r, T scale) -> T {
-        if (plain) return x;
-        if (r < n - 1) return scale * x;
-        return (r == n - 1) ? Tr<T>::one() : Tr<T>::zero();
-    };
+    // v = scale * xh + e_(n-1), xh = raw column with the entries >= nz zeroed.  Everything below is linear in
+    // v, so the products are formed with xh (known at launch) and the larfg scalars -- the end of a chain
+    // load -> reduce -> sqrt/reciprocals -- are only applied to the reduced partial sums.
+    const int nz = plain ? n : n - 1;
+    const int one_at = plain ? -1 : n - 1;
+    const T zero = Tr<T>::zero();
+    auto xhat = [&](int r) -> T { return sel(r < nz, a.xbuf[min(r, max(nz - 1, 0))], zero); };
+    auto unit = [&](int r) -> T { return sel(r == one_at, Tr<T>::one(), zero); };
 
-    // ---------------- issue the first batch of loads ----------------
-    T alpha_early = Tr<T>::zero();
-    if (!plain && wave == 0) alpha_early = *a.alphaSlot;   // consumed by the scalar prologue: issue with everything else
-    const int nt = (n + HT - 1) / HT;
-    const int ntiles = nt * (nt + 1) / 2;
-    __shared__ T xcs[2][HT];   // raw column entries of v for the current / next tile
-    T av[16];
-    T xr = Tr<T>::zero();
-    int I = 0, J = 0, t = hb, buf = 0;
-    // gemv item
-    int g_which = 0, g_kk = 0, g_rbeg = 0, g_rend = 0, g_ch = 0;
-    bool g_ok = false;
-    const int wbase = a.np - a.nb;
-    auto load_tile = [&](int b) {
-        tile_decode(t, I, J);
-        const int r0 = I * HT, c0 = J * HT, r = r0 + lane;
-        const bool diag = (I == J);
-        xr = xraw(r);
+    // ---------------- scalar loads first: they are waited for first (vmcnt retires in order) ----------------
+    // raw, unconditional (clamped) loads; selects and sums happen in scalars(), after everything is issued
+    const bool does_scalars = !plain && (is_gemv || wave == 0);
+    const int nnp = plain ? 1 : a.nblkA;
+    T alpha_early = zero;
+    double npl[NPL];
+    {
+        const T* ap = plain ? a.xbuf : a.alphaSlot;          // any valid address in plain mode, value unused
+        const double* np = plain ? reinterpret_cast<const double*>(a.xbuf) : a.NP;
+        alpha_early = *ap;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int cc = c0 + wave * 16 + j;
-            bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
-            T v = Tr<T>::zero();
-            if (ok) v = a.A[(size_t)r + (size_t)cc * a.lda];
-            if (diag && r == cc) v = Tr<T>::realpart(v);
-            av[j] = v;
+        for (int u = 0; u < NPL; ++u) npl[u] = np[min(lane + 64 * u, nnp - 1)];
+    }
+    // larfg scalars, evaluated redundantly by every lane of the calling wave (wave-uniform result)
+    auto scalars = [&]() -> T {
+        double ss = 0.0;
+        for (int q = lane + 64 * NPL; q < a.nblkA; q += 64) ss += a.NP[q];
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) npl[u] = (lane + 64 * u < a.nblkA) ? npl[u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < NPL; u += 4) ss += (npl[u] + npl[u + 1]) + (npl[u + 2] + npl[u + 3]);
+        ss = wave_sum(ss);
+        double beta;
+        T tau, scale;
+        larfg_scalars<T>(ss, alpha_early, beta, tau, scale);
+        if (blockIdx.x == 0 && tid == 0) {
+            a.e[i - 1] = beta;
+            a.tau[i - 1] = tau;
         }
-        if (tid < HT) xcs[b][tid] = xraw(c0 + tid);
+        return scale;
     };
+    (void)does_scalars;
+
     if (is_gemv) {
+        // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk), one item per wave
         const int npo = a.np - 1 - i;
+        const int wbase = a.np - a.nb;
         const int item = (int)blockIdx.x * 4 + wave;
-        g_ok = item < 2 * npo * a.nchunk;
-        if (g_ok) {
-            g_ch = item / (2 * npo);
-            int rem = item % (2 * npo);
-            g_which = rem / npo; g_kk = rem % npo;
-            int k = i + 1 + g_kk;
-            const T* src = g_which == 0 ? a.A + (size_t)k * a.lda : a.W + (size_t)(k - wbase) * a.ldw;
-            g_rbeg = g_ch * CH; g_rend = min(n, g_rbeg + CH);
+        if (item >= 2 * npo * a.nchunk) return;
+        const int ch = item / (2 * npo);
+        const int rem = item % (2 * npo);
+        const int which = rem / npo, kk = rem % npo;
+        const int k = i + 1 + kk;
+        const T* src = which == 0 ? a.A + (size_t)k * a.lda : a.W + (size_t)(k - wbase) * a.ldw;
+        const int rbeg = ch * CH;
+        T s = Tr<T>::zero(), eone = Tr<T>::zero();
+        T sv[8], xv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int r = g_rbeg + lane + 64 * j;
-                av[j] = (r < g_rend) ? src[r] : Tr<T>::zero();
-                av[8 + j] = (r < g_rend) ? a.xbuf[r] : Tr<T>::zero();
-            }
+        for (int j = 0; j < 8; ++j) {   // raw loads, all in flight before the first use
+            int r = rbeg + lane + 64 * j;
+            sv[j] = src[min(r, n - 1)];
+            xv[j] = a.xbuf[min(r, max(nz - 1, 0))];
         }
-    } else if (t < ntiles) {
-        load_tile(0);
-    }
-
-    // ---------------- scalar prologue (every workgroup, deterministic) ----------------
-    if (!plain) {
-        if (wave == 0) {
-            double ss = 0.0, np4[4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int q = lane + 64 * u;
-                double t = a.NP[min(q, a.nblkA - 1)];
-                np4[u] = (q < a.nblkA) ? t : 0.0;
-            }
-            for (int q = lane + 256; q < a.nblkA; q += 64) ss += a.NP[q];
-            ss += (np4[0] + np4[1]) + (np4[2] + np4[3]);
-            ss = wave_sum(ss);
-            if (lane == 0) {
-                double beta;
-                T tau, scale;
-                larfg_scalars<T>(ss, alpha_early, beta, tau, scale);
-                sc_scale = scale;
-                if (blockIdx.x == 0) {
-                    a.e[i - 1] = beta;
-                    a.tau[i - 1] = tau;
-                }
-            }
+        for (int j = 0; j < 8; ++j) {
+            int r = rbeg + lane + 64 * j;
+            const T sj = sel(r < n, sv[j], zero);
+            fmac_(s, sj, sel(r < nz, xv[j], zero));
+            eone = sel(r == one_at, conj_(sj), eone);
         }
-    }
-    __syncthreads();
-    const T scale = plain ? Tr<T>::one() : sc_scale;
-
-    if (is_gemv) {
-        // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk)
-        if (g_ok) {
-            T s = Tr<T>::zero();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int r = g_rbeg + lane + 64 * j;
-                fmac_(s, av[j], vfix(av[8 + j], r, scale));
-            }
-            s = wave_sum(s);
-            if (lane == 0) a.Zp[(size_t)(g_ch * 2 + g_which) * NBMAX + g_kk] = s;
-        }
+        const T scale = scalars();
+        s = wave_sum(scale * s + eone);
+        if (lane == 0) a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk] = s;
         return;
     }
+
+    // ---------------- Hermitian mat-vec tiles ----------------
+    const int nt = (n + HT - 1) / HT;
+    const int ntiles = nt * (nt + 1) / 2;
+    T av[16], xr_raw = zero, lc_raw = zero;   // raw loads of the tile in flight
+    int I = 0, J = 0, t = hb, buf = 0;
+    // Issue the loads of tile t: unconditional, clamped addresses, nothing else in between (a select on a
+    // loaded value is where the compiler waits; masks are applied when the tile is consumed).  The column
+    // entries of v go first: their hand-over to LDS then waits for that one load and leaves the rest in flight.
+    // All four waves store the same 64 values (a store only wave 0 executes lets the compiler sink the load).
+    auto issue_tile = [&](int b) {
+        tile_decode(t, I, J);
+        const int r0 = I * HT, c0 = J * HT, r = r0 + lane;
+        const T xc_raw = a.xbuf[min(c0 + lane, max(nz - 1, 0))];
+        lc_raw = a.A[(size_t)min(r, n - 1) + (size_t)(n - 1) * a.lda];   // column n-1: the e_(n-1) part of v
+        xr_raw = a.xbuf[min(r, max(nz - 1, 0))];
+        const size_t roff = (size_t)min(r, n - 1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, n - 1) * a.lda];
+        __builtin_amdgcn_sched_barrier(0);
+        xcs[b][lane] = sel(c0 + lane < nz, xc_raw, zero);
+    };
+    if (t < ntiles) issue_tile(0);
+    TSTAMP(0, 0, T0);   // loads issued, xcs written
+    __syncthreads();
+    TSTAMP(0, 1, T0);
+    T scale = Tr<T>::one();
+    if (!plain && wave == 0) scale = scalars();   // under the latency of the tile loads
+    TSTAMP(0, 2, T0);
 
     T Sacc = Tr<T>::zero();
     while (t < ntiles) {
         const int r0 = I * HT, c0 = J * HT;
         const bool diag = (I == J);
         const int r = r0 + lane;
-        const T vr = vfix(xr, r, scale);
+        const int Ic = I, Jc = J;
+        const T xr = sel(r < nz, xr_raw, zero);
+        T lastc = sel(!plain && J == nt - 1 && r <= n - 1, lc_raw, zero);
+        lastc = sel(r == n - 1, Tr<T>::realpart(lastc), lastc);
         T yI = Tr<T>::zero();
         T tj[16];
+        if (!diag && r0 + HT <= n && c0 + HT <= n) {
+            // interior tile (the bulk of the bytes): no masks
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int cc = c0 + wave * 16 + j;
-            T vc = vfix(xcs[buf][wave * 16 + j], cc, scale);
-            fma_(yI, av[j], vc);
-            T p = Tr<T>::zero();
-            if (!(diag && r == cc)) fmac_(p, av[j], vr);
-            tj[j] = p;
+            for (int j = 0; j < 16; ++j) {
+                fma_(yI, av[j], xcs[buf][wave * 16 + j]);
+                T p = Tr<T>::zero();
+                fmac_(p, av[j], xr);
+                tj[j] = p;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int cc = c0 + wave * 16 + j;
+                const bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
+                const bool dg = diag && r == cc;
+                T v = sel(ok, av[j], zero);
+                v = sel(dg, Tr<T>::realpart(v), v);
+                fma_(yI, v, xcs[buf][wave * 16 + j]);
+                T p = Tr<T>::zero();
+                fmac_(p, sel(dg, zero, v), xr);
+                tj[j] = p;
+            }
         }
-        T tval;
-        transpose_reduce16<T, 16>(tj, lane, tval);
+        T tval = transpose_reduce16<T>(tj, lane);
+        TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
         redy[wave][lane] = yI;
         if ((lane & 3) == 0) redt[wave * 16 + (lane >> 2)] = tval;
-        // own row/column entries of v for the S partial (tid < 64)
-        T vI = Tr<T>::zero(), vJ = Tr<T>::zero();
-        if (tid < 64) { vI = vfix(xraw(r0 + tid), r0 + tid, scale); vJ = vfix(xcs[buf][tid], c0 + tid, scale); }
-        const int Ic = I, Jc = J;
         t += a.gh;
 #if EIG_MV_PREFETCH
-        if (t < ntiles) load_tile(buf ^ 1);   // next tile's loads fly while the barriers drain
+        if (t < ntiles) issue_tile(buf ^ 1);   // next tile's loads fly while the barriers drain
 #endif
         __syncthreads();
-        if (tid < 64) {
-            T yv = (redy[0][tid] + redy[1][tid]) + (redy[2][tid] + redy[3][tid]);
-            T tv = redt[tid];
+        if (wave == 0) {
+            T yv = scale * ((redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane])) + lastc;
+            T tv = scale * redt[lane];
+            T vI = scale * xr + unit(r0 + lane);
+            T vJ = scale * xcs[buf][lane] + unit(c0 + lane);
             if (diag) {
                 T s = yv + tv;
-                a.P[(size_t)Jc * a.ldp + r0 + tid] = s;
+                a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
                 fmac_(Sacc, vI, s);
-                if (!plain && c0 + tid < n) a.A[(size_t)(c0 + tid) + (size_t)i * a.lda] = vJ;
+                if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
             } else {
-                a.P[(size_t)Jc * a.ldp + r0 + tid] = yv;
-                a.P[(size_t)Ic * a.ldp + c0 + tid] = tv;
+                a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
+                a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
                 fmac_(Sacc, vI, yv);
                 fmac_(Sacc, vJ, tv);
             }
         }
         buf ^= 1;
 #if !EIG_MV_PREFETCH
-        if (t < ntiles) load_tile(buf);
+        if (t < ntiles) issue_tile(buf);
 #endif
+        TSTAMP(0, 4, T0);   // partials stored
         __syncthreads();
     }
     if (wave == 0) {
         Sacc = wave_sum(Sacc);
         if (lane == 0) a.S[hb] = Sacc;
     }
+    TSTAMP(0, 5, T0);       // end
 }
 
 // y = sum of the hemv partials (stand-alone hemv entry point only)
@@ -622,7 +611,7 @@ template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N) {
     s.S = c.scratch<T>("trd_S", 8192);
     int nchunk = (N + CH - 1) / CH;
     s.Zp = c.scratch<T>("trd_Zp", (size_t)(nchunk + 1) * 2 * NBMAX);
-    s.NP = c.scratch<double>("trd_NP", (size_t)(N / RR) + 64);
+    s.NP = c.scratch<double>("trd_NP", (size_t)(N / RR + 1) * NPW + 64);
     s.alphaSlot = c.scratch<T>("trd_alpha", 8);
     return s;
 }
@@ -642,7 +631,12 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         a.i = i;
         a.gh = gh_prev; a.nchunk = nchunk_prev;
         int gA = (i + 1 + RR - 1) / RR;
-        if (!mv_only) hipLaunchKernelGGL((panel_row_kernel<T>), dim3(gA), dim3(256), 0, st, a, do_finish, do_update);
+        if (!mv_only) {
+            const int c = i + 1, npo = do_finish ? np - 1 - c : 0, ntc = (c + HT - 1) / HT;
+            if (!do_finish) launch_row<T, false, true>(st, gA, a, npo, ntc);
+            else if (do_update) launch_row<T, true, true>(st, gA, a, npo, ntc);
+            else launch_row<T, true, false>(st, gA, a, npo, ntc);
+        }
         if (last) break;
         // mat-vec for column i (v has i entries)
         int n = i;
@@ -650,7 +644,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         int nchunk = (n + CH - 1) / CH;
         int npo = np - 1 - i;
         int gg = (2 * npo * nchunk + 3) / 4;
-        a.nblkA = gA; a.gh = gh; a.nchunk = nchunk;
+        a.nblkA = gA * NPW; a.gh = gh; a.nchunk = nchunk;
         hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(256), 0, st, a, 0, gg);
         if (nlaunch) ++*nlaunch;
         if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
@@ -692,7 +686,7 @@ template <class T>
 void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes) {
     if (nb <= 0 || nb > NBMAX) nb = NBMAX;
     TrdScratch<T> sc = trd_scratch<T>(c, N);
-    std::vector<double> ones((size_t)(N / RR) + 64, 1.0);
+    std::vector<double> ones((size_t)(N / RR + 1) * NPW + 64, 1.0);
     EIG_HIP(hipMemcpyAsync(sc.NP, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, st));
     T one = Tr<T>::one();
     EIG_HIP(hipMemcpyAsync(sc.alphaSlot, &one, sizeof(T), hipMemcpyHostToDevice, st));
