@@ -205,6 +205,17 @@ def hegvdx(A_d, B_d, il, iu, ws=None, skip_host_copy=False):
     return info, ws
 
 
+def diaghg(H_d, S_d, m, ws=None):
+    """The QE / LAXlib call pattern (cdiaghg_gpu / rdiaghg_gpu, external to the reference repo; README.md:2,11):
+    H v = e S v with H, S resident on the device and left INTACT, lowest m eigenpairs, results consumed on the
+    device (`_skip_host_copy=.true.`, zhegvdx_gpu.F90:171-180).  Returns (info, e_d[:m], v_d[:, :m] as an (m, N)
+    column-major view, ws).  Mirrors eigensolver_gpu_amd/fortran/laxlib_glue.F90."""
+    N = H_d.shape[0]
+    info, ws = hegvdx(H_d.clone(), S_d.clone(), 1, m, ws=ws, skip_host_copy=True)
+    _sync()
+    return info, ws.w[:m], ws.Z[:m], ws
+
+
 def phase_times():
     """Per-phase ms of the last driver call: potrf, gst, trd, stedc(host), back-transform, trsm, d2h, total."""
     buf = (ctypes.c_double * 8)()

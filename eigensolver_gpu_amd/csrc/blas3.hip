@@ -16,6 +16,7 @@
 //    C) and triangular-output filtering are folded into the operand loader / epilogue, so no
 //    operand is ever physically modified (the reference stashes/zeros/restores blocks of A).
 #include "blas3.h"
+#include "lanes.h"
 
 namespace eig {
 
@@ -631,9 +632,11 @@ constexpr int DBL = DB + 1;  // LDS leading dimension
 // 64x64 upper Cholesky (optional) followed by the inverse of the factor, one workgroup.
 // Register-resident: thread (tr, tc) = (tid/16, tid%16) owns the 4x4 block rows 4tr.., cols 4tc..
 // of U (and of X = U^-1).  Each of the 64 elimination steps broadcasts one row (and for the inverse
-// one column) through a double-buffered LDS line and costs a single barrier; every thread redoes the
-// scalar sqrt/reciprocal itself.  (~20 us instead of ~200 us for the LDS-resident column version;
-// this kernel sits on the critical path of potrf N/64 times.)
+// one column) through a double-buffered LDS line and costs a single barrier.  The step loops are
+// unrolled over the position inside the 4x4 block so that every register index is static; the pivot
+// is a Newton-refined v_rsq_f64 (no IEEE sqrt / division on the 64-step chain) and its reciprocal is
+// kept for the inversion, which then has no division at all.  This kernel sits on the critical path
+// of potrf N/64 times.
 //   do_chol = 1: block <- chol(block) (upper), written back; info <- first bad pivot (1-based, global)
 //   inverse written to invU (DB x DB, ld DB, identity-padded, zero below the diagonal).
 template <class T>
@@ -641,6 +644,7 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                                                          int* info) {
     __shared__ T rowb[2][DB];
     __shared__ T colb[2][DB];
+    __shared__ T dinvs[DB];   // reciprocals of the diagonal of U
     const int tid = threadIdx.x;
     const int tr = tid >> 4, tc = tid & 15;
     const int blk = (k0_single >= 0) ? k0_single / DB : blockIdx.x;
@@ -655,64 +659,64 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int r = 4 * tr + i, cc = 4 * tc + j;
-            T v = Tr<T>::zero();
-            if (r < nb && cc < nb && r <= cc) v = Ublk[(size_t)r + (size_t)cc * ldu];
-            else if (r == cc) v = Tr<T>::one();
-            u[i][j] = v;
+            const bool in = r < nb && cc < nb && r <= cc;
+            T v = Ublk[(size_t)min(r, nb - 1) + (size_t)min(cc, nb - 1) * ldu];
+            u[i][j] = sel(in, v, sel(r == cc, Tr<T>::one(), Tr<T>::zero()));
             x[i][j] = (r == cc) ? Tr<T>::one() : Tr<T>::zero();
         }
 
     const bool upper_blk = tc >= tr;   // only blocks on or above the block diagonal carry data
     const bool diag_blk = tc == tr;
     if (do_chol) {
-        for (int j = 0; j < DB; ++j) {
-            const int jb = j >> 2, jj = j & 3, buf = j & 1;
-            if (tr == jb) {
+        for (int jb = 0; jb < DB / 4; ++jb) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i == jj) {
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * jb + jj, buf = jj & 1;
+                if (tr == jb) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = u[i][q];
-                    }
-            }
-            __syncthreads();
-            double d = real_(rowb[buf][j]);
-            if (!(d > 0.0)) {
-                if (tid == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
-                d = 1.0;
-            }
-            if (upper_blk && tr >= jb) {   // rows >= j only; roles are static inside a block phase
-                const double piv = sqrt(d), ipiv = 1.0 / piv;
-                T uc[4], ur[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
-                    ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
+                    for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = u[jj][q];
                 }
-                if (tr > jb) {
+                __syncthreads();
+                double d = real_(rowb[buf][j]);
+                if (!(d > 0.0)) {
+                    if (tid == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
+                    d = 1.0;
+                }
+                if (upper_blk && tr >= jb) {   // rows >= j only; roles are static inside a block phase
+                    const double ipiv = fast_rsqrt(d);
+                    double piv = d * ipiv;
+                    piv = fma(fma(-piv, piv, d), 0.5 * ipiv, piv);
+                    T uc[4], ur[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int q = 0; q < 4; ++q) {
+                        uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
+                        ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
+                    }
+                    if (tr > jb) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (!diag_blk || q >= i) {
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
                                 T t = Tr<T>::zero();
                                 fmac_(t, ur[i], uc[q]);
-                                u[i][q] = u[i][q] - t;
+                                u[i][q] = u[i][q] - t;    // (entries below the diagonal of a diagonal block are never read)
                             }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    } else {
+                        if (diag_blk) dinvs[j] = Tr<T>::make(ipiv, 0.0);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            if (i == jj) {
-                                if (!diag_blk || q > jj) u[i][q] = uc[q];
-                                else if (q == jj) u[i][q] = Tr<T>::make(piv, 0.0);
-                            } else if (i > jj && (!diag_blk || q >= i)) {
+                            if (!diag_blk || q > jj) u[jj][q] = uc[q];
+                            else if (q == jj) u[jj][q] = Tr<T>::make(piv, 0.0);
+                        }
+#pragma unroll
+                        for (int i = jj + 1; i < 4; ++i)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
                                 T t = Tr<T>::zero();
                                 fmac_(t, ur[i], uc[q]);
                                 u[i][q] = u[i][q] - t;
                             }
-                        }
+                    }
                 }
             }
         }
@@ -723,59 +727,58 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                 int r = 4 * tr + i, cc = 4 * tc + q;
                 if (r < nb && cc < nb && r <= cc) Ublk[(size_t)r + (size_t)cc * ldu] = u[i][q];
             }
-        __syncthreads();
+    } else if (diag_blk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T dgn = u[i][i];
+            dinvs[4 * tr + i] = conj_(dgn) * (1.0 / abs2_(dgn));
+        }
     }
+    __syncthreads();
 
     // X = U^-1 by right-looking back substitution on the rows, bottom up
-    for (int i2 = DB - 1; i2 >= 0; --i2) {
-        const int ib = i2 >> 2, ii = i2 & 3, buf = i2 & 1;
-        if (tr == ib) {
+    for (int ib = DB / 4 - 1; ib >= 0; --ib) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i == ii) {
+        for (int ii = 3; ii >= 0; --ii) {
+            const int i2 = 4 * ib + ii, buf = ii & 1;
+            if (tr == ib) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = x[i][q];
-                }
-        }
-        if (tc == ib) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (q == ii) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) colb[buf][4 * tr + i] = u[i][q];
-                }
-        }
-        __syncthreads();
-        if (upper_blk && tr <= ib && tc >= ib) {   // rows <= i2, columns >= i2
-            T dgn = colb[buf][i2];
-            T dinv = conj_(dgn) * (1.0 / abs2_(dgn));
-            T xr[4], uc2[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)   (zero for c < i2)
-                uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
+                for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = x[ii][q];
             }
-            if (tr < ib) {
+            if (tc == ib) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) colb[buf][4 * tr + i] = u[i][ii];
+            }
+            __syncthreads();
+            if (upper_blk && tr <= ib && tc >= ib) {   // rows <= i2, columns >= i2
+                const T dinv = dinvs[i2];
+                T xr[4], uc2[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        T t = Tr<T>::zero();
-                        fma_(t, uc2[i], xr[q]);
-                        x[i][q] = x[i][q] - t;
-                    }
-            } else {
+                for (int q = 0; q < 4; ++q) {
+                    xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)   (zero for c < i2)
+                    uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
+                }
+                if (tr < ib) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (i == ii) x[i][q] = xr[q];
-                        else if (i < ii) {
+                        for (int q = 0; q < 4; ++q) {
                             T t = Tr<T>::zero();
                             fma_(t, uc2[i], xr[q]);
                             x[i][q] = x[i][q] - t;
                         }
-                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[ii][q] = xr[q];
+#pragma unroll
+                    for (int i = 0; i < ii; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            T t = Tr<T>::zero();
+                            fma_(t, uc2[i], xr[q]);
+                            x[i][q] = x[i][q] - t;
+                        }
+                }
             }
         }
     }
@@ -979,8 +982,11 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
-    // EIGSOLVE_GST: 0 = symmetric recursion (N^3 flops, ~16N/64 small launches), 1 = two full solves (2N^3 flops,
-    // ~4N/64 large launches), default: two solves from N = 256 up (C3: 28.3 -> 14.4 ms).
+    // EIGSOLVE_GST: 0 = symmetric recursion (2/3 N^3 multiply-adds, ~16N/64 small launches), 1 = two full solves
+    // (N^3 multiply-adds, ~4N/64 large launches), default: two solves from N = 256 up (C3: 28.3 -> 14.4 ms).
+    // A hybrid (symmetric recursion on the top one or two levels, two solves below) was measured slower
+    // (15.3 ms): the upper-triangle her2k (528 tiles on 512 resident workgroups) and the K-trimmed hemm
+    // quantise badly; see DESIGN.md.
     static const int mode = getenv("EIGSOLVE_GST") ? atoi(getenv("EIGSOLVE_GST")) : -1;
     const bool two = mode < 0 ? (N >= 256) : (mode == 1);
     if (two) hegst_two_solves(c, st, N, A, lda, U, ldu);
@@ -1020,16 +1026,20 @@ template <class T> __global__ void __launch_bounds__(256) copy_upper_kernel(int 
     if (r == cc) v = Tr<T>::realpart(v);
     A[(size_t)r + (size_t)cc * lda] = v;
 }
-template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+template <class T> static void hegst_two_solves_at(Ctx& c, hipStream_t st, int N, int k0, T* A, int lda, const T* U, int ldu) {
     if (N <= 0) return;
+    T* Ablk = A + (size_t)k0 + (size_t)k0 * lda;
     T* F = c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", (size_t)N * N);
     const int nb32 = (N + 31) / 32;
-    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)A, lda, F, N);
-    trsm_LUC(c, st, N, N, U, ldu, 0, F, N);   // F <- U^-H F
-    trsm_RUN(c, st, N, N, U, ldu, 0, F, N);   // F <- F U^-1
+    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)Ablk, lda, F, N);
+    trsm_LUC(c, st, N, N, U, ldu, k0, F, N);   // F <- U(k0.., k0..)^-H F
+    trsm_RUN(c, st, N, N, U, ldu, k0, F, N);   // F <- F U(k0.., k0..)^-1
     size_t tot = (size_t)N * N;
-    hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, A, lda);
+    hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, Ablk, lda);
     EIG_HIP(hipGetLastError());
+}
+template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+    hegst_two_solves_at(c, st, N, 0, A, lda, U, ldu);
 }
 
 template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {

@@ -118,4 +118,13 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// 1/sqrt(x) to ~1 ulp (x normal, positive): v_rsq_f64 + two Newton steps
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
 }  // namespace eig

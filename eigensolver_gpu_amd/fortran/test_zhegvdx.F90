@@ -8,12 +8,13 @@ program test_zhegvdx
   use eigsolve_vars
   use nvtx_inters
   use zhegvdx_gpu
+  use eigsolve_laxlib_glue
   implicit none
   integer :: N, m, lda, il, iu, info, i, j, k, nargs
   integer :: lwork, lrwork, liwork, lwork_d, lrwork_d
   character(len=32) :: arg
   complex(8), allocatable, target :: A(:,:), B(:,:), T1(:,:), Zh(:,:), work(:)
-  real(8), allocatable, target :: wh(:), rwork(:)
+  real(8), allocatable, target :: wh(:), rwork(:), wg(:)
   integer, allocatable, target :: iwork(:)
   type(c_ptr) :: A_d, B_d, Z_d, w_d, work_d, rwork_d
   integer(c_int) :: istat
@@ -84,6 +85,23 @@ program test_zhegvdx
     write(*,*) 'RESIDUAL CHECK FAILED'
     stop 2
   end if
+
+  ! the LAXlib call pattern (cdiaghg_gpu): H, S stay intact on the device, results stay on the device
+  istat = hipMemcpy(A_d, c_loc(A), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  istat = hipMemcpy(B_d, c_loc(B), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  call cdiaghg_gpu_glue(N, m, A_d, B_d, N, w_d, Z_d, info)
+  if (info /= 0) then
+    write(*,*) 'cdiaghg_gpu_glue failed'
+    stop 3
+  end if
+  allocate(wg(N))
+  istat = hipMemcpy(c_loc(wg), w_d, int(8, c_size_t) * N, hipMemcpyDeviceToHost)
+  if (maxval(abs(wg(1:m) - wh(1:m))) > 0.0d0) then
+    write(*,*) 'cdiaghg_gpu_glue: eigenvalues differ from the direct call', maxval(abs(wg(1:m) - wh(1:m)))
+    stop 4
+  end if
+  write(*,*) 'cdiaghg_gpu_glue: eigenvalues identical to the direct call'
+  call diaghg_glue_release()
   write(*,*) 'PASSED'
 
 contains

@@ -386,6 +386,7 @@ def test_fortran_dropin_driver(env):
     out = subprocess.run([exe, "300", "75"], capture_output=True, text=True, env=envv, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASSED" in out.stdout
+    assert "cdiaghg_gpu_glue: eigenvalues identical" in out.stdout     # LAXlib-style glue module (8(f) row 4)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -505,6 +506,52 @@ def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
     assert np.abs(w - wl).max() <= 50 * n * EPS * nrm
     assert np.abs(A @ Z - Z * w[il - 1:iu]).max() <= 50 * n * EPS * nrm
     assert np.abs(Z.conj().T @ Z - np.eye(m)).max() <= 50 * n * EPS
+
+
+# ---------------------------------------------------------------------------------------------
+# il > 1 (both paths honour il for the vectors; w always returns all N values)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,il,iu", [(64, 2, 2), (129, 17, 80), (300, 250, 300)])
+def test_hegvdx_il_greater_than_one(env, cplx, n, il, iu):
+    torch, oracle, api = env
+    import scipy.linalg as sl
+    A = oracle.gen_spd_fast(n, 6000 + n, cplx)
+    B = oracle.gen_spd_fast(n, 7000 + n, cplx, shift=float(n))
+    info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), il, iu)
+    assert info == 0
+    m = iu - il + 1
+    wl = sl.eigh(A, B, eigvals_only=True)
+    assert oracle.compare_1d(wl, w)[0] <= 1e-12                       # all N eigenvalues, ascending
+    wsel = w[il - 1:iu]
+    R = A @ Z - (B @ Z) * wsel                                        # columns 1..m of Z are pairs il..iu
+    assert np.linalg.norm(R) / np.linalg.norm(A) <= n * EPS
+    assert np.abs(Z.conj().T @ B @ Z - np.eye(m)).max() <= 1e-11
+    Zd = np.asfortranarray(api.to_host(ws.Z, n, m))
+    assert np.array_equal(Zd, Z)
+
+
+# ---------------------------------------------------------------------------------------------
+# the caller one step above the boundary (QE LAXlib cdiaghg_gpu / rdiaghg_gpu pattern)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cplx", [False, True])
+def test_laxlib_call_pattern(env, cplx):
+    torch, oracle, api = env
+    n, m = 200, 40
+    H = oracle.gen_spd_fast(n, 8000 + n, cplx)
+    S = oracle.gen_spd_fast(n, 9000 + n, cplx, shift=float(n))
+    H_d, S_d = api.to_device(np.triu(H)), api.to_device(np.triu(S))
+    H0, S0 = H_d.clone(), S_d.clone()
+    info, e_d, v_d, ws = api.diaghg(H_d, S_d, m)
+    assert info == 0
+    assert torch.equal(H_d, H0) and torch.equal(S_d, S0)              # inputs intact
+    e = e_d.cpu().numpy()
+    V = np.asfortranarray(api.to_host(ws.Z, n, m))
+    assert oracle.residual(H, S, e, V) <= n * EPS
+    info2, ws2, w2, Z2 = run_driver(api, np.triu(H), np.triu(S), 1, m)  # same numbers as the plain driver call
+    assert np.array_equal(w2[:m], e) and np.array_equal(Z2, V)
+    info3, e3, v3, _ = api.diaghg(H_d, S_d, m, ws=ws)                 # workspace reuse, bit-identical
+    assert info3 == 0 and torch.equal(e3, e_d)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
