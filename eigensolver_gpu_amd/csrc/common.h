@@ -97,6 +97,9 @@ enum Phase { PH_POTRF = 0, PH_GST, PH_TRD, PH_STEDC, PH_BT, PH_TRSM, PH_D2H, PH_
 // the host dstedc at N=4096); EIGSOLVE_TRIDIAG=host / eigsolve_set_option("tridiag", 0) restores the
 // reference behaviour (host LAPACK).
 constexpr int kTridiagDefault = 1;
+// Reflectors per block in the back-transformation: 64 (the reference's larfb width, zheevd_gpu.F90:113-131) or
+// 128 = two 64-blocks with a merged T factor (twice the K of the rank-k update: twice the arithmetic intensity).
+constexpr int kBtNbDefault = 128;
 
 struct Ctx {
     int dev = -1;
@@ -112,7 +115,7 @@ struct Ctx {
     int n_cu = 256;
     // tunables
     int trd_nb = 64;
-    int bt_nb = 64;
+    int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default

@@ -112,7 +112,8 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
-    if (c->bt_nb < 1 || c->bt_nb > 64) c->bt_nb = 64;
+    if (c->bt_nb < 1 || c->bt_nb > 128) c->bt_nb = kBtNbDefault;
+    if (c->bt_nb > 64) c->bt_nb = 128;
     t_ctx[dev] = c;
     return *c;
 }
@@ -223,7 +224,7 @@ int eigsolve_set_option(const char* name, int value) {
         eig::Ctx& c = eig::ctx();
         std::string s(name ? name : "");
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
-        else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 64) ? 64 : value;
+        else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 128) ? eig::kBtNbDefault : (value > 64 ? 128 : value);
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value != 0;

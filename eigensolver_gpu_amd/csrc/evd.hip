@@ -29,9 +29,14 @@ template <class T> __global__ void __launch_bounds__(256) widen_kernel(int n, in
 template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, int nb2, T* Tall, int ldt, const T* tau_all) {
     __shared__ T t[64][65];  // t[col][row]
     const int tx = threadIdx.x;
-    const int i0 = blockIdx.x * nb2;
-    const int K = (k - i0 < nb2) ? k - i0 : nb2;
-    T* Tm = Tall + (size_t)blockIdx.x * ldt * ldt;
+    // reflector blocks of nb2 <= 128 = up to two 64-wide halves, one workgroup per half
+    const int halves = nb2 > 64 ? 2 : 1;
+    const int b = blockIdx.x / halves, sub = blockIdx.x % halves;
+    const int ibb = (k - b * nb2 < nb2) ? k - b * nb2 : nb2;   // reflectors in block b
+    const int K = (ibb - sub * 64 < 64) ? ibb - sub * 64 : 64;
+    if (K <= 0) return;
+    const int i0 = b * nb2 + sub * 64;
+    T* Tm = Tall + (size_t)b * ldt * ldt + (size_t)sub * 64 * (1 + ldt);
     const T* tau = tau_all + i0;
     for (int j = 0; j < K; ++j) {
         T v = Tr<T>::zero();
@@ -54,6 +59,69 @@ template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, 
         if (tx < K) Tm[(size_t)tx + (size_t)j * ldt] = t[j][tx];
 }
 
+// Two 64-reflector T factors of one 128-block -> the T factor of the 128 reflectors:
+//   (I - V1 T1 V1^H)(I - V0 T0 V0^H) = I - [V0 V1] [[T0, 0], [T10, T1]] [V0 V1]^H,  T10 = -T1 (V1^H V0) T0.
+// On entry the (1,0) block of the buffer still holds S10 = V1^H V0 (from the V^H V product), the diagonal
+// blocks hold T0, T1 (lower, zero above the diagonal).  One workgroup per 128-block; thread (tr,tc) owns a
+// 4x4 block of the 64x64 result; X = S10 T0 goes through LDS.
+template <class T> __global__ void __launch_bounds__(256) merge_T_kernel(int k, int nb2, T* Tall, int ldt) {
+    __shared__ T X[64][65];   // X[c][r]
+    const int b = blockIdx.x;
+    const int ibb = (k - b * nb2 < nb2) ? k - b * nb2 : nb2;
+    const int K1 = ibb - 64;   // rows of the (1,0) block
+    if (K1 <= 0) return;
+    T* Tb = Tall + (size_t)b * ldt * ldt;
+    const T* T0 = Tb;
+    T* S10 = Tb + 64;
+    const T* T1 = Tb + (size_t)64 * (1 + ldt);
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Tr<T>::zero();
+    // X(r, c) = sum_p S10(r, p) T0(p, c),  T0 lower: p >= c
+    for (int p = 4 * tc; p < 64; ++p) {
+        T sr[4], tcv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sr[i] = (4 * tr + i < K1) ? S10[(size_t)(4 * tr + i) + (size_t)p * ldt] : Tr<T>::zero();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tcv[j] = (p >= 4 * tc + j) ? T0[(size_t)p + (size_t)(4 * tc + j) * ldt] : Tr<T>::zero();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma_(acc[i][j], sr[i], tcv[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X[4 * tc + j][4 * tr + i] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Tr<T>::zero();
+    // T10(r, c) = - sum_p T1(r, p) X(p, c),  T1 lower: p <= r
+    const int pmax = min(4 * tr + 3, K1 - 1);
+    for (int p = 0; p <= pmax; ++p) {
+        T t1[4], xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t1[i] = (4 * tr + i < K1 && p <= 4 * tr + i) ? T1[(size_t)(4 * tr + i) + (size_t)p * ldt] : Tr<T>::zero();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = X[4 * tc + j][p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma_(acc[i][j], t1[i], xv[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * tr + i < K1) S10[(size_t)(4 * tr + i) + (size_t)(4 * tc + j) * ldt] = -acc[i][j];
+}
+
 // ---- back-transformation ------------------------------------------------------------------------
 // Q = H_{N-2} ... H_0 applied to C = Z(0:N, 0:m) in blocks of nb2 reflectors, ascending
 // (zheevd_gpu.F90:113-131).  All T factors are built first (they do not depend on C), then each
@@ -65,7 +133,7 @@ static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const
     if (k <= 0) return;
     if (nb2 > N) nb2 = N;
     const int nblk = (k + nb2 - 1) / nb2;
-    const int ldt = 64;
+    const int ldt = nb2 > 64 ? 128 : 64;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
@@ -78,7 +146,9 @@ static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const
         Epi e; e.uplo = 2;
         gemm_splitk<T>(c, st, ib, ib, mi, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tb, ldt, 256, e);
     }
-    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
+    const int halves = nb2 > 64 ? 2 : 1;
+    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk * halves), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
+    if (halves == 2) hipLaunchKernelGGL((merge_T_kernel<T>), dim3(nblk), dim3(256), 0, st, k, nb2, Tall, ldt);
     EIG_HIP(hipGetLastError());
 }
 
@@ -88,10 +158,10 @@ static void bt_apply(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, 
     if (k <= 0 || m <= 0) return;
     if (nb2 > N) nb2 = N;
     const int nblk = (k + nb2 - 1) / nb2;
-    const int ldt = 64;
+    const int ldt = nb2 > 64 ? 128 : 64;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
-    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 64);
-    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 64);
+    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 128);
+    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 128);
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
         const T* V = A + (size_t)(i + 1) * lda;
