@@ -100,6 +100,7 @@ constexpr int kTridiagDefault = 1;
 // Reflectors per block in the back-transformation: 64 (the reference's larfb width, zheevd_gpu.F90:113-131) or
 // 128 = two 64-blocks with a merged T factor (twice the K of the rank-k update: twice the arithmetic intensity).
 constexpr int kBtNbDefault = 128;
+constexpr int kOverlapDefault = 0;
 
 struct Ctx {
     int dev = -1;
@@ -119,8 +120,9 @@ struct Ctx {
     int hemv_blocks = 0;  // 0 = auto
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
-    int overlap = 0;         // 1: potrf || first half of gst, T factors || tridiagonal solve on the second stream.
-                             // Measured: -3 % latency of an isolated solve, but -15 % throughput with 2 solves in flight -> off
+    int overlap = kOverlapDefault;   // bit 0: potrf || first half of gst (uses the symmetric hegst recursion: -3 % latency of an
+                             // isolated solve, -15 % throughput with 2 solves in flight); bit 1: larft T factors on the second
+                             // stream while the tridiagonal eigenproblem is solved (zheevd_gpu.F90:125 overlaps the same work)
     struct GraphEntry {
         hipGraphExec_t exec = nullptr;
         hipGraph_t graph = nullptr;

@@ -109,7 +109,7 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
     if (const char* e = getenv("EIGSOLVE_GRAPH")) c->use_graph = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) & 3;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
     if (c->bt_nb < 1 || c->bt_nb > 128) c->bt_nb = kBtNbDefault;
@@ -227,7 +227,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 128) ? eig::kBtNbDefault : (value > 64 ? 128 : value);
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
         else if (s == "graph") c.use_graph = value > 0;
-        else if (s == "overlap") c.overlap = value != 0;
+        else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

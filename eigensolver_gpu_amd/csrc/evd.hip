@@ -254,8 +254,9 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     pt.end(PH_TRD);
     // larft T factors depend only on the reflectors: build them on the second stream while the tridiagonal
     // eigenproblem is being solved (zheevd_gpu.F90:125 does the same per block with stream1/stream2)
-    hipStream_t stT = c.overlap ? c.s2 : st;
-    if (c.overlap) {
+    const bool ovT = (c.overlap & 2) != 0;
+    hipStream_t stT = ovT ? c.s2 : st;
+    if (ovT) {
         EIG_HIP(hipEventRecord(c.evA, st));
         EIG_HIP(hipStreamWaitEvent(stT, c.evA, 0));
         bt_build_T<T>(c, stT, N, Vsrc, ldv, tau_bt, c.bt_nb);
@@ -309,7 +310,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     c.phase_ms[PH_STEDC] += now_ms() - t0;
     }
     pt.begin(PH_BT);
-    if (c.overlap) EIG_HIP(hipStreamWaitEvent(st, c.evB, 0));
+    if (ovT) EIG_HIP(hipStreamWaitEvent(st, c.evB, 0));
     else bt_build_T<T>(c, st, N, Vsrc, ldv, tau_bt, c.bt_nb);
     bt_apply<T>(c, st, N, m, Vsrc, ldv, Z, ldz, c.bt_nb);
     pt.end(PH_BT);

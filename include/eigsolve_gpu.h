@@ -44,9 +44,12 @@ int eigsolve_set_host_threads(int nthreads);
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
  * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
- * "overlap": 1 = independent launch chains of one solve run on two streams (second half of potrf with the
- * first half of gst; larft T factors with the tridiagonal eigensolver): -3 % latency for an isolated solve, but
- * -15 % throughput when several solves are in flight on the GPU; 0 (default) = single stream.  Returns 0 / -1 (unknown name). */
+ * "overlap": bit mask of independent launch chains of one solve that run on a second stream: bit 0 = second half of
+ * potrf with the first half of gst, bit 1 = larft T factors with the tridiagonal eigensolver (zheevd_gpu.F90:125
+ * overlaps the same work).  Measured on MI355X: once a context drives two hardware queues every dependent launch
+ * gets slower (bit 1 alone: back-transform -1.1 ms, whole solve +13 ms), so 0 (default) = single stream.
+ * "bt_nb": 64 (the reference's larfb width) or 128 (default: two 64-blocks with a merged T factor).
+ * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 
 /* nvtxStartRange / nvtxEndRange (lib_eigsolve/toolbox.F90:71-97) -> roctx ranges when
