@@ -32,7 +32,22 @@ template <class T> struct GemmArgs {
     int kchunk;      // >0: split-K, blockIdx.z owns [z*kchunk, (z+1)*kchunk)
     T* P;            // split-K partial output (M x N per split, ld = M)
     size_t pstride;
+    int tri;         // 1: 1-D grid over the tiles of the stored triangle only (see tile_of)
 };
+
+// Tile owned by this workgroup.  Triangular outputs (epi.uplo) on a square tile grid are launched as a 1-D grid
+// over the ACTIVE tiles only: with a 2-D grid and an early exit the hardware's round-robin of workgroup ids over
+// the 8 XCDs leaves them unevenly loaded (order-1984 upper update: 496 tiles <= 512 resident slots, yet one XCD
+// receives 76 tiles for its 64 slots and the launch takes two rounds; measured 27 -> 4x TFLOP/s).
+template <class T> __device__ __forceinline__ void tile_of(const GemmArgs<T>& g, int& bx, int& by) {
+    if (!g.tri) { bx = blockIdx.x; by = blockIdx.y; return; }
+    const int t = blockIdx.x;
+    int q = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((q + 1) * (q + 2) / 2 <= t) ++q;
+    while (q * (q + 1) / 2 > t) --q;
+    const int r = t - q * (q + 1) / 2;   // r <= q
+    if (g.epi.uplo == 1) { bx = r; by = q; } else { bx = q; by = r; }
+}
 
 template <class T>
 __device__ __forceinline__ T fetch(const Operand<T>& o, int idx, int k, int nidx, int kend) {
@@ -93,7 +108,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
     double* Bs = sm + NPL * ASZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    int tbx, tby;
+    tile_of(g, tbx, tby);
+    const int i0 = tbx * BM, j0 = tby * BN;
     if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
     if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
 
@@ -315,7 +332,9 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
     __shared__ double sm[2 * STG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
+    int tbx, tby;
+    tile_of(g, tbx, tby);
+    const int i0 = tbx * BM, j0 = tby * BN;
     if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
     if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
 
@@ -526,9 +545,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
 static bool g_use_fast = getenv("EIGSOLVE_GEMM_GENERIC") == nullptr;
 
 template <class T, int BM, int BN>
-static void launch_gemm(hipStream_t st, const GemmArgs<T>& g, int splits) {
+static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits) {
     constexpr int BK = (BM * BN <= 64 * 32) ? BKS : BKL;
-    dim3 grid((g.M + BM - 1) / BM, (g.N + BN - 1) / BN, splits);
+    GemmArgs<T> g = g_in;
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    dim3 grid(tm, tn, splits);
+    g.tri = 0;
+    if (g.epi.uplo != 0 && BM == BN && tm == tn) {
+        g.tri = 1;
+        grid = dim3((unsigned)((long)tm * (tm + 1) / 2), 1, splits);
+    }
     dim3 block(256);
     int ta = g.A.trans, tb = g.B.trans;
     const bool cat = g.A.k1 != INT_MAX || g.B.k1 != INT_MAX;
@@ -589,6 +615,46 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
     GemmArgs<T> g;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
     g.kchunk = 0; g.P = nullptr; g.pstride = 0;
+    // Tile quantisation: a grid whose 64x64 tiles do not fill the resident workgroups (2 per CU) a whole number of
+    // times leaves most of the chip idle in the last round (an upper-triangle update of order 2048 is 528 tiles on
+    // 512 slots: 2 rounds for 1.03 rounds of work).  When K is long enough, split it so that the work items are
+    // short and many; the partial sums cost one pass over C and one more launch.
+    if constexpr (Tr<T>::cx) {
+        static const bool auto_on = getenv("EIGSOLVE_GEMM_AUTOSPLIT") ? atoi(getenv("EIGSOLVE_GEMM_AUTOSPLIT")) != 0 : true;
+        const bool masked = A.mask != M_NONE || Bt.mask != M_NONE;
+        if (auto_on && !masked && epi.inplace == 0 && K >= 1024) {
+            const long tm = (M + 63) / 64, tn = (N + 63) / 64, tmin = tm < tn ? tm : tn;
+            long tiles = tm * tn;
+            if (epi.uplo != 0) tiles = tmin * (tmin + 1) / 2 + (epi.uplo == 1 ? (tn - tmin) * tm : (tm - tmin) * tn);
+            const long slots = 2L * c.n_cu;
+            if (tiles >= c.n_cu / 2) {
+                const double u = 0.305;   // us per unit of K for one 64x64 complex tile with 2 workgroups per CU
+                int best = 1;
+                double bestc = (double)((tiles + slots - 1) / slots) * K * u;
+                const int cand[] = {2, 3, 4, 6, 8};
+                for (int sp : cand) {
+                    if (K / sp < 256) break;
+                    if ((double)M * N * sp * sizeof(T) > 512e6) break;
+                    double cost = (double)((tiles * sp + slots - 1) / slots) * ((double)K / sp) * u +
+                                  2.0 * tiles * 4096.0 * sizeof(T) * sp / 5.0e6 + 6.0;
+                    if (cost < 0.9 * bestc) { bestc = cost; best = sp; }
+                }
+                if (best > 1) {
+                    int kchunk = ((K + best - 1) / best + 63) & ~63;
+                    g.kchunk = kchunk;
+                    int splits = (K + kchunk - 1) / kchunk;
+                    g.pstride = (size_t)M * N;
+                    g.P = c.scratch<T>("splitk", g.pstride * splits);
+                    dispatch_gemm(c, st, g, splits);
+                    size_t total = (size_t)M * N;
+                    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N,
+                                       splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi);
+                    EIG_HIP(hipGetLastError());
+                    return;
+                }
+            }
+        }
+    }
     dispatch_gemm(c, st, g, 1);
 }
 
@@ -627,6 +693,8 @@ template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* 
 // 64x64 base kernels (one workgroup, matrix resident in LDS)
 // ------------------------------------------------------------------------------------------
 constexpr int DB = kDiagBlk;
+constexpr int kGstModeDefault = 2;   // see hegst_upper
+constexpr int kGstHybridThr = 2048;
 constexpr int DBL = DB + 1;  // LDS leading dimension
 
 // 64x64 upper Cholesky (optional) followed by the inverse of the factor, one workgroup.
@@ -981,16 +1049,19 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
 
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
+template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr);
+
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
-    // EIGSOLVE_GST: 0 = symmetric recursion (2/3 N^3 multiply-adds, ~16N/64 small launches), 1 = two full solves
-    // (N^3 multiply-adds, ~4N/64 large launches), default: two solves from N = 256 up (C3: 28.3 -> 14.4 ms).
-    // A hybrid (symmetric recursion on the top one or two levels, two solves below) was measured slower
-    // (15.3 ms): the upper-triangle her2k (528 tiles on 512 resident workgroups) and the K-trimmed hemm
-    // quantise badly; see DESIGN.md.
-    static const int mode = getenv("EIGSOLVE_GST") ? atoi(getenv("EIGSOLVE_GST")) : -1;
-    const bool two = mode < 0 ? (N >= 256) : (mode == 1);
-    if (two) hegst_two_solves(c, st, N, A, lda, U, ldu);
-    else hegst_rec(c, st, N, 0, A, lda, U, ldu);
+    // EIGSOLVE_GST: 0 = symmetric recursion down to 64x64 blocks (2/3 N^3 multiply-adds, ~16N/64 small launches),
+    //               1 = two full triangular solves (N^3 multiply-adds, ~4N/64 large launches),
+    //               2 = hybrid (default): the symmetric algorithm (zhegst_gpu.F90:51-107) on the large levels, where
+    //                   every operation is a chip-filling MFMA launch, two solves on diagonal blocks of order
+    //                   <= EIGSOLVE_GST_THR (2048).  C3 (N=4096): 28.3 / 14.2 / 13.3 ms, batch 11.9 -> 12.4 problems/s.
+    static const int mode = getenv("EIGSOLVE_GST") ? atoi(getenv("EIGSOLVE_GST")) : kGstModeDefault;
+    static const int thr = getenv("EIGSOLVE_GST_THR") ? atoi(getenv("EIGSOLVE_GST_THR")) : kGstHybridThr;
+    if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
+    else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
+    else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr < 256 ? 256 : thr);
 }
 
 // ---- hegst as two full triangular solves ------------------------------------------------------------
@@ -1040,6 +1111,44 @@ template <class T> static void hegst_two_solves_at(Ctx& c, hipStream_t st, int N
 }
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
     hegst_two_solves_at(c, st, N, 0, A, lda, U, ldu);
+}
+
+// One level of the symmetric algorithm (zhegst_gpu.F90:51-107 with the block size = half the matrix): every
+// operation is a large MFMA launch.  Diagonal blocks of order <= thr fall back to the two-solve form.
+template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr) {
+    if (n <= 0) return;
+    if (n <= thr) {
+        hegst_two_solves_at(c, st, n, k0, A, lda, U, ldu);
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr);
+    T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
+    T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
+    T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
+    const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
+    const T mhalf = Tr<T>::make(-0.5, 0.0);
+    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda);                     // A12 <- U11^-H A12
+    // Herm(A11) completed once into scratch: the two hemm steps are then plain full-rate gemms
+    T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
+    {
+        const int nb32 = (n1 + 31) / 32;
+        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
+    }
+    auto hemm_half = [&]() {                                          // A12 -= 1/2 Herm(A11) U12
+        gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
+    };
+    hemm_half();
+    {
+        Operand<T> Ao, Bo;                                            // A22 -= A12^H U12 + U12^H A12 (upper)
+        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
+        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+    }
+    hemm_half();
+    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda);               // A12 <- A12 U22^-1
+    hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr);
 }
 
 template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
