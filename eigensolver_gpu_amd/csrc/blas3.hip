@@ -693,8 +693,6 @@ template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* 
 // 64x64 base kernels (one workgroup, matrix resident in LDS)
 // ------------------------------------------------------------------------------------------
 constexpr int DB = kDiagBlk;
-constexpr int kGstModeDefault = 2;   // see hegst_upper
-constexpr int kGstHybridThr = 2048;
 constexpr int DBL = DB + 1;  // LDS leading dimension
 
 // 64x64 upper Cholesky (optional) followed by the inverse of the factor, one workgroup.
@@ -1057,11 +1055,10 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     //               2 = hybrid (default): the symmetric algorithm (zhegst_gpu.F90:51-107) on the large levels, where
     //                   every operation is a chip-filling MFMA launch, two solves on diagonal blocks of order
     //                   <= EIGSOLVE_GST_THR (2048).  C3 (N=4096): 28.3 / 14.2 / 13.3 ms, batch 11.9 -> 12.4 problems/s.
-    static const int mode = getenv("EIGSOLVE_GST") ? atoi(getenv("EIGSOLVE_GST")) : kGstModeDefault;
-    static const int thr = getenv("EIGSOLVE_GST_THR") ? atoi(getenv("EIGSOLVE_GST_THR")) : kGstHybridThr;
+    const int mode = c.gst_mode, thr = c.gst_thr;   // EIGSOLVE_GST / EIGSOLVE_GST_THR, eigsolve_set_option("gst" / "gst_thr")
     if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
     else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
-    else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr < 256 ? 256 : thr);
+    else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr);
 }
 
 // ---- hegst as two full triangular solves ------------------------------------------------------------

@@ -101,6 +101,10 @@ constexpr int kTridiagDefault = 1;
 // 128 = two 64-blocks with a merged T factor (twice the K of the rank-k update: twice the arithmetic intensity).
 constexpr int kBtNbDefault = 128;
 constexpr int kOverlapDefault = 0;
+// Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
+// algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
+constexpr int kGstModeDefault = 2;
+constexpr int kGstThrDefault = 2048;
 
 struct Ctx {
     int dev = -1;
@@ -129,6 +133,8 @@ struct Ctx {
         const void* ptrs[16] = {};
     };
     std::map<std::string, GraphEntry> graphs;
+    int gst_mode = kGstModeDefault;
+    int gst_thr = kGstThrDefault;
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
 
     template <class T> T* scratch(const char* name, size_t count) {

@@ -110,6 +110,10 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
     if (const char* e = getenv("EIGSOLVE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) & 3;
+    if (const char* e = getenv("EIGSOLVE_GST")) c->gst_mode = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_GST_THR")) c->gst_thr = atoi(e);
+    if (c->gst_mode < 0 || c->gst_mode > 2) c->gst_mode = kGstModeDefault;
+    if (c->gst_thr < 256) c->gst_thr = 256;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
     if (c->bt_nb < 1 || c->bt_nb > 128) c->bt_nb = kBtNbDefault;
@@ -228,6 +232,8 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
+        else if (s == "gst") c.gst_mode = (value < 0 || value > 2) ? eig::kGstModeDefault : value;
+        else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

@@ -39,7 +39,7 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap"};
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr"};
  * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
@@ -49,6 +49,9 @@ int eigsolve_set_host_threads(int nthreads);
  * overlaps the same work).  Measured on MI355X: once a context drives two hardware queues every dependent launch
  * gets slower (bit 1 alone: back-transform -1.1 ms, whole solve +13 ms), so 0 (default) = single stream.
  * "bt_nb": 64 (the reference's larfb width) or 128 (default: two 64-blocks with a merged T factor).
+ * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
+ * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
+ * larger than "gst_thr" (default 2048), two solves below.
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

@@ -508,6 +508,72 @@ def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
     assert np.abs(Z.conj().T @ Z - np.eye(m)).max() <= 50 * n * EPS
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+def test_algorithm_options_agree(env, cplx):
+    """The three forms of the reduction to standard form (symmetric recursion / two full solves / hybrid) and the two
+    back-transformation block widths (64 = the reference's larfb width, 128 = merged T factors) are the same
+    mathematics: results agree to rounding, each is bit-reproducible."""
+    torch, oracle, api = env
+    n, m = 700, 180
+    A = oracle.gen_spd_fast(n, 4100 + n, cplx)
+    B = oracle.gen_spd_fast(n, 5100 + n, cplx, shift=float(n))
+    res = {}
+    try:
+        for key, opts in (("default", {}), ("gst0", {"gst": 0}), ("gst1", {"gst": 1}), ("gst2", {"gst": 2, "gst_thr": 256}),
+                          ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128})):
+            for k, v in opts.items():
+                assert api.set_option(k, v) == 0
+            info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
+            assert info == 0
+            assert oracle.residual(A, B, w, Z) <= n * EPS
+            res[key] = (w, Z)
+            for k in opts:
+                api.set_option(k, -1 if k == "gst" else 0)
+    finally:
+        for k in ("gst", "gst_thr", "bt_nb"):
+            api.set_option(k, -1 if k == "gst" else 0)
+    w0, Z0 = res["default"]
+    for key, (w, Z) in res.items():
+        assert oracle.compare_1d(w0, w)[0] <= 1e-13, key
+        assert oracle.compare_abs2d(Z0, Z)[0] <= 1e-9, key
+
+
+def test_order_above_8192_tail_paths(env):
+    """N > 8192, odd: the tail loops of the panel kernels (more than 128 hemv stripes, more than 8 gemv chunks, more
+    than 1024 norm partials), remainder panels and non-power-of-two recursion splits.  Well-conditioned family, so the
+    strict N*eps residual gate applies."""
+    torch, oracle, api = env
+    n, m = 8257, 32
+    A = oracle.gen_spd_fast(n, 11, False)
+    B = oracle.gen_spd_fast(n, 12, False, shift=float(n))
+    info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
+    assert info == 0
+    assert oracle.residual(A, B, w, Z) <= n * EPS
+    assert np.abs(Z.T @ (B @ Z) - np.eye(m)).max() <= 1e-11
+    assert np.all(np.diff(w) >= 0)
+
+
+def test_triangular_update_tile_counts(env):
+    """Upper-triangle rank-2k updates on tile counts around the resident-workgroup count (1-D triangular grids,
+    auto split-K): values against numpy, strict lower triangle untouched."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(5)
+    for n, k in ((1984, 512), (2050, 1024), (333, 1100)):
+        V = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+        W = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+        C = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        C = C + C.conj().T
+        Cd = api.to_device(C)
+        api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+        got = api.to_host(Cd, n, n)
+        ref = C - (V @ W.conj().T + W @ V.conj().T)
+        iu = np.triu_indices(n)
+        scale = np.abs(ref).max()
+        assert np.abs(got[iu] - ref[iu]).max() <= 50 * k * EPS * scale
+        il = np.tril_indices(n, -1)
+        assert np.array_equal(got[il], C[il])
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY.md 8(f) row 2: il > 1 (both paths honour il for the vectors; w always returns all N values)
 # ---------------------------------------------------------------------------------------------
