@@ -127,4 +127,12 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
+// sqrt(x) to ~1 ulp for x >= 0 (x normal or zero): x * rsqrt(x) with one residual correction
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double y = fast_rsqrt(x > 0.0 ? x : 1.0);
+    double g = x * y;
+    g = fma(fma(-g, g, x), 0.5 * y, g);
+    return g;
+}
+
 }  // namespace eig

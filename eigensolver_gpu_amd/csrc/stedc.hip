@@ -332,6 +332,47 @@ __global__ void __launch_bounds__(256) dc_gather_kernel(const MergeDesc* md, con
     Qg[(size_t)(m.off + row) + (size_t)(m.off + g) * ldq] = Q[(size_t)(m.off + row) + (size_t)src_all[m.off + g] * ldq];
 }
 
+// Batched eigenvector update C = Qg(n x k) * S2(k x k) for the small merges of the lower tree levels (n <= 256): one
+// launch per level instead of two MFMA launches per merge (levels n = 64, 128, 256 of an N = 4096 problem are 224
+// launches of a few microseconds each).  Qg carries explicit zeros where the column types have none, so the plain
+// product is exact.  32x32 output tiles, 256 threads x (2x2), K in chunks of 32 through LDS.
+__global__ void __launch_bounds__(256) dc_update_small_kernel(const MergeDesc* md, const double* Qg, const double* S2, double* C, int ldq) {
+    const MergeDesc m = md[blockIdx.z];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    if (r0 >= m.n || c0 >= m.k) return;
+    __shared__ double As[32][33], Bs[32][33];   // As[p][r], Bs[p][c]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const double* Qb = Qg + (size_t)m.off + (size_t)m.off * ldq;
+    const double* Sb = S2 + (size_t)m.off + (size_t)m.off * ldq;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    for (int p0 = 0; p0 < m.k; p0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int lo = e & 31, hi = e >> 5;
+            // A(r0 + lo, p0 + hi): consecutive lanes along the rows (contiguous); B(p0 + lo, c0 + hi) likewise
+            const int r = r0 + lo, pa = p0 + hi, pb = p0 + lo, cc = c0 + hi;
+            const double av = Qb[(size_t)min(r, m.n - 1) + (size_t)min(pa, m.k - 1) * ldq];
+            const double bv = Sb[(size_t)min(pb, m.k - 1) + (size_t)min(cc, m.k - 1) * ldq];
+            As[hi][lo] = (r < m.n && pa < m.k) ? av : 0.0;
+            Bs[lo][hi] = (pb < m.k && cc < m.k) ? bv : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 32; ++pp) {
+            const double x0 = As[pp][2 * tx], x1 = As[pp][2 * tx + 1], y0 = Bs[pp][2 * ty], y1 = Bs[pp][2 * ty + 1];
+            a00 = fma(x0, y0, a00); a01 = fma(x0, y1, a01); a10 = fma(x1, y0, a10); a11 = fma(x1, y1, a11);
+        }
+        __syncthreads();
+    }
+    double* Cb = C + (size_t)m.off + (size_t)m.off * ldq;
+    const int r = r0 + 2 * tx, cc = c0 + 2 * ty;
+    if (r < m.n && cc < m.k) Cb[(size_t)r + (size_t)cc * ldq] = a00;
+    if (r + 1 < m.n && cc < m.k) Cb[(size_t)(r + 1) + (size_t)cc * ldq] = a10;
+    if (r < m.n && cc + 1 < m.k) Cb[(size_t)r + (size_t)(cc + 1) * ldq] = a01;
+    if (r + 1 < m.n && cc + 1 < m.k) Cb[(size_t)(r + 1) + (size_t)(cc + 1) * ldq] = a11;
+}
+
 // ranks of the new eigenvalues (non-deflated roots, ascending) and of the deflated values (ascending)
 // in the merged order.
 __global__ void __launch_bounds__(256) dc_rank_kernel(const MergeDesc* md, const double* lam_all, const double* dval_all, int* pos_nd, int* pos_df) {
@@ -629,7 +670,13 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             hipLaunchKernelGGL(dc_gather_kernel, dim3((nmax + 255) / 256, kmax, nm), dim3(256), 0, st, (const MergeDesc*)d_md,
                                (const int*)d_src, (const double*)Qcur, Qg, ldq);
             EIG_HIP(hipGetLastError());
-            // eigenvector update on the MFMA engine: Qtmp (= S buffer) <- Qg * S2, two gemms per merge
+            // eigenvector update Qtmp (= S buffer) <- Qg * S2: small merges batched in one launch, large ones as two
+            // gemms per merge on the MFMA engine
+            if (nmax <= 256) {
+                hipLaunchKernelGGL(dc_update_small_kernel, dim3((nmax + 31) / 32, (kmax + 31) / 32, nm), dim3(256), 0, st,
+                                   (const MergeDesc*)d_md, (const double*)Qg, (const double*)S2, S, ldq);
+                EIG_HIP(hipGetLastError());
+            } else
             for (const MergeDesc& m : h_md) {
                 if (m.k == 0) continue;
                 const int k12 = m.k1 + m.k2, k23 = m.k2 + m.k3;

@@ -72,12 +72,12 @@ template <class T> __device__ __forceinline__ void larfg_scalars(double ss, T al
         scale = Tr<T>::zero();
         return;
     }
-    double xnorm = sqrt(ss);
+    double xnorm = fast_sqrt(ss);
     double rv1 = fabs(ar), rv2 = fabs(ai);
     double scal = fmax(fmax(rv1, rv2), xnorm);
     double inv = fast_rcp(scal);
     rv1 *= inv; rv2 *= inv; xnorm *= inv;
-    beta = -copysign(scal * sqrt(rv1 * rv1 + rv2 * rv2 + xnorm * xnorm), ar);
+    beta = -copysign(scal * fast_sqrt(rv1 * rv1 + rv2 * rv2 + xnorm * xnorm), ar);
     double rb = fast_rcp(beta);
     tau = Tr<T>::make((beta - ar) * rb, -ai * rb);
     if constexpr (Tr<T>::cx) {
