@@ -130,10 +130,14 @@ struct MergeDesc {
     double rho;          // normalised: |2 rho_in|
 };
 
-// z[col] = Q(zrow[col], col) * zscale[col]
-__global__ void __launch_bounds__(256) dc_zgather_kernel(int N, const double* Q, int ldq, const int* zrow, const double* zscale, double* z) {
+// zD[col] = Q(zrow[col], col) * zscale[col], zD[N + col] = D[col]  (one contiguous download for the host deflation scan)
+__global__ void __launch_bounds__(256) dc_zgather_kernel(int N, const double* Q, int ldq, const int* zrow, const double* zscale,
+                                                         const double* D, double* zD) {
     int col = blockIdx.x * 256 + threadIdx.x;
-    if (col < N) z[col] = Q[(size_t)zrow[col] + (size_t)col * ldq] * zscale[col];
+    if (col < N) {
+        zD[col] = Q[(size_t)zrow[col] + (size_t)col * ldq] * zscale[col];
+        zD[N + col] = D[col];
+    }
 }
 
 // Givens rotations of column pairs (deflation of close poles), in order, rows of the merge only.
@@ -490,16 +494,34 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     double* S2 = c.scratch<double>("dc_S2", NN);
     double* Da = c.scratch<double>("dc_Da", (size_t)N);
     double* Db = c.scratch<double>("dc_Db", (size_t)N);
-    double* dvec = c.scratch<double>("dc_dvec", (size_t)8 * N);   // dmod|e|z|dl|w|lam|zhat|dval
-    double* d_dmod = dvec, *d_e = dvec + N, *d_z = dvec + 2 * (size_t)N, *d_dl = dvec + 3 * (size_t)N, *d_w = dvec + 4 * (size_t)N,
-           *d_lam = dvec + 5 * (size_t)N, *d_zhat = dvec + 6 * (size_t)N, *d_dval = dvec + 7 * (size_t)N;
-    int* ivec = c.scratch<int>("dc_ivec", (size_t)10 * N + 64);
-    int* d_zrow = ivec, *d_grp = ivec + N, *d_src = ivec + 2 * (size_t)N, *d_dcol = ivec + 3 * (size_t)N, *d_posnd = ivec + 4 * (size_t)N,
-        *d_posdf = ivec + 5 * (size_t)N, *d_rp = ivec + 6 * (size_t)N, *d_rq = ivec + 7 * (size_t)N, *d_leafoff = ivec + 8 * (size_t)N,
-        *d_leafn = ivec + 9 * (size_t)N;
-    double* d_zscale = c.scratch<double>("dc_zscale", (size_t)3 * N);
-    double* d_rc = d_zscale + N, *d_rs = d_zscale + 2 * (size_t)N;
-    MergeDesc* d_md = c.scratch<MergeDesc>("dc_md", (size_t)N / 2 + 8);
+    double* dvec = c.scratch<double>("dc_dvec", (size_t)6 * N);   // dmod|e|z,D (download pair)|lam|zhat
+    double* d_dmod = dvec, *d_e = dvec + N, *d_z = dvec + 2 * (size_t)N, *d_lam = dvec + 4 * (size_t)N, *d_zhat = dvec + 5 * (size_t)N;
+    int* ivec = c.scratch<int>("dc_ivec", (size_t)4 * N + 64);
+    int* d_posnd = ivec, *d_posdf = ivec + N, *d_leafoff = ivec + 2 * (size_t)N, *d_leafn = ivec + 3 * (size_t)N;
+    // everything the host deflation scan produces for a level travels in ONE pinned -> device copy:
+    //   doubles dl|w|dval|rc|rs, MergeDesc md[], ints grp|src|dcol|rp|rq
+    const size_t nmd = (size_t)N / 2 + 8;
+    const size_t pack_bytes = sizeof(double) * 5 * (size_t)N + sizeof(MergeDesc) * nmd + sizeof(int) * 5 * (size_t)N;
+    char* d_pack = reinterpret_cast<char*>(c.scratch_bytes("dc_pack", pack_bytes));
+    char* h_pack = reinterpret_cast<char*>(c.host_scratch_bytes("dc_pack_h", pack_bytes));
+    auto carve = [&](char* base) {
+        struct P { double *dl, *w, *dval, *rc, *rs; MergeDesc* md; int *grp, *src, *dcol, *rp, *rq; } q;
+        double* dp = reinterpret_cast<double*>(base);
+        q.dl = dp; q.w = dp + N; q.dval = dp + 2 * (size_t)N; q.rc = dp + 3 * (size_t)N; q.rs = dp + 4 * (size_t)N;
+        q.md = reinterpret_cast<MergeDesc*>(dp + 5 * (size_t)N);
+        int* ip = reinterpret_cast<int*>(q.md + nmd);
+        q.grp = ip; q.src = ip + N; q.dcol = ip + 2 * (size_t)N; q.rp = ip + 3 * (size_t)N; q.rq = ip + 4 * (size_t)N;
+        return q;
+    };
+    auto dq = carve(d_pack);
+    auto hq = carve(h_pack);
+    double* d_dl = dq.dl, *d_w = dq.w, *d_dval = dq.dval, *d_rc = dq.rc, *d_rs = dq.rs;
+    MergeDesc* d_md = dq.md;
+    int* d_grp = dq.grp, *d_src = dq.src, *d_dcol = dq.dcol, *d_rp = dq.rp, *d_rq = dq.rq;
+    // z rows / scales of every level depend on the tree and the signs of e only: uploaded once
+    int* d_zrow_all = nullptr;
+    double* d_zscale_all = nullptr;
+    double* h_zD = reinterpret_cast<double*>(c.host_scratch_bytes("dc_zD_h", sizeof(double) * 2 * (size_t)N));
     int* d_info = c.d_info + 1;
 
     EIG_HIP(hipMemsetAsync(Qa, 0, NN * sizeof(double), st));
@@ -521,10 +543,37 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     }
 
     double* Qcur = Qa; double* Qnext = Qb; double* Dcur = Da; double* Dnext = Db;
-    std::vector<double> hz(N), hD(N), h_dl(N), h_w(N), h_dval(N), h_zscale(N), h_rc(N), h_rs(N);
-    std::vector<int> h_zrow(N), h_grp(N), h_src(N), h_dcol(N), h_rp(N), h_rq(N);
+    double* hz = h_zD, *hD = h_zD + N;
+    double* h_dl = hq.dl, *h_w = hq.w, *h_dval = hq.dval, *h_rc = hq.rc, *h_rs = hq.rs;
+    int* h_grp = hq.grp, *h_src = hq.src, *h_dcol = hq.dcol, *h_rp = hq.rp, *h_rq = hq.rq;
+    MergeDesc* h_mdp = hq.md;
     std::vector<MergeDesc> h_md;
     const double EPSD = 2.220446049250313e-16;
+    {
+        // z rows / scales for all levels
+        d_zrow_all = c.scratch<int>("dc_zrow_all", (size_t)(nlevels + 1) * N);
+        d_zscale_all = c.scratch<double>("dc_zscale_all", (size_t)(nlevels + 1) * N);
+        int* h_zr = reinterpret_cast<int*>(c.host_scratch_bytes("dc_zrow_h", sizeof(int) * (size_t)(nlevels + 1) * N));
+        double* h_zs = reinterpret_cast<double*>(c.host_scratch_bytes("dc_zscale_h", sizeof(double) * (size_t)(nlevels + 1) * N));
+        for (int level = 1; level <= nlevels; ++level) {
+            int* zr = h_zr + (size_t)level * N;
+            double* zs = h_zs + (size_t)level * N;
+            for (int i = 0; i < N; ++i) { zr[i] = 0; zs[i] = 0.0; }
+            for (int id = 0; id < (int)nodes.size(); ++id) {
+                const Node& nd = nodes[id];
+                if (nd.left < 0 || nd.level != level) continue;
+                int n1 = nodes[nd.left].n;
+                double rho_in = e[nodes[nd.right].off - 1];
+                double sgn = rho_in >= 0.0 ? 1.0 : -1.0;
+                for (int i = 0; i < nd.n; ++i) {
+                    zr[nd.off + i] = (i < n1) ? nd.off + n1 - 1 : nd.off + n1;
+                    zs[nd.off + i] = ((i < n1) ? 1.0 : sgn) * M_SQRT1_2;
+                }
+            }
+        }
+        EIG_HIP(hipMemcpyAsync(d_zrow_all, h_zr, sizeof(int) * (size_t)(nlevels + 1) * N, hipMemcpyHostToDevice, st));
+        EIG_HIP(hipMemcpyAsync(d_zscale_all, h_zs, sizeof(double) * (size_t)(nlevels + 1) * N, hipMemcpyHostToDevice, st));
+    }
 
     for (int level = 1; level <= nlevels; ++level) {
         // merges of this level
@@ -542,26 +591,10 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             // find parent level
             (void)is_root_of_done;
         }
-        // z rows / scales
-        for (int id : ms) {
-            const Node& nd = nodes[id];
-            int n1 = nodes[nd.left].n;
-            double rho_in = e[nodes[nd.right].off - 1];
-            double sgn = rho_in >= 0.0 ? 1.0 : -1.0;
-            for (int i = 0; i < nd.n; ++i) {
-                h_zrow[nd.off + i] = (i < n1) ? nd.off + n1 - 1 : nd.off + n1;
-                h_zscale[nd.off + i] = ((i < n1) ? 1.0 : sgn) * M_SQRT1_2;
-            }
-        }
-        // columns outside this level's merges keep zrow valid (any in-range value)
-        for (int i = 0; i < N; ++i)
-            if (h_zrow[i] < 0 || h_zrow[i] >= N) h_zrow[i] = 0;
-        EIG_HIP(hipMemcpyAsync(d_zrow, h_zrow.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_zscale, h_zscale.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(dc_zgather_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (const double*)Qcur, ldq, (const int*)d_zrow,
-                           (const double*)d_zscale, d_z);
-        EIG_HIP(hipMemcpyAsync(hz.data(), d_z, sizeof(double) * N, hipMemcpyDeviceToHost, st));
-        EIG_HIP(hipMemcpyAsync(hD.data(), Dcur, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(dc_zgather_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, (const double*)Qcur, ldq,
+                           (const int*)(d_zrow_all + (size_t)level * N), (const double*)(d_zscale_all + (size_t)level * N),
+                           (const double*)Dcur, d_z);
+        EIG_HIP(hipMemcpyAsync(h_zD, d_z, sizeof(double) * 2 * (size_t)N, hipMemcpyDeviceToHost, st));
         EIG_HIP(hipStreamSynchronize(st));
 
         // ---- deflation scan per merge (host, sequential in j; LAPACK dlaed2's logic) ----
@@ -644,18 +677,9 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             h_md.push_back(m);
         }
         const int nm = (int)h_md.size();
-        EIG_HIP(hipMemcpyAsync(d_md, h_md.data(), sizeof(MergeDesc) * nm, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_grp, h_grp.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_src, h_src.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_dcol, h_dcol.data(), sizeof(int) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_dl, h_dl.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_w, h_w.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_dval, h_dval.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
+        for (int q = 0; q < nm; ++q) h_mdp[q] = h_md[q];
+        EIG_HIP(hipMemcpyAsync(d_pack, h_pack, pack_bytes, hipMemcpyHostToDevice, st));
         if (rot_total > 0) {
-            EIG_HIP(hipMemcpyAsync(d_rp, h_rp.data(), sizeof(int) * rot_total, hipMemcpyHostToDevice, st));
-            EIG_HIP(hipMemcpyAsync(d_rq, h_rq.data(), sizeof(int) * rot_total, hipMemcpyHostToDevice, st));
-            EIG_HIP(hipMemcpyAsync(d_rc, h_rc.data(), sizeof(double) * rot_total, hipMemcpyHostToDevice, st));
-            EIG_HIP(hipMemcpyAsync(d_rs, h_rs.data(), sizeof(double) * rot_total, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(dc_rotate_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const int*)d_rp,
                                (const int*)d_rq, (const double*)d_rc, (const double*)d_rs, Qcur, ldq);
         }
