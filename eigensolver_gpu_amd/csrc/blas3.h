@@ -78,9 +78,11 @@ template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb
 template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
 
 // Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)).
-template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X <- U^-1 X
-template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X <- U^-H X
-template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx);  // X(mxn) <- X U^-1
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X <- U^-1 X
+template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X <- U^-H X
+template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X(mxn) <- X U^-1
+// merged 256x256 inverse diagonal blocks for base = 256 (needs the 64-block inverses of potrf_upper / build_invU)
+template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
 
 // A <- U^-H A U^-1 (upper triangle only is read/written).
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);

@@ -909,9 +909,9 @@ __global__ void __launch_bounds__(256) hegs2_block_kernel(int nb, T* Ablk, int l
 // ------------------------------------------------------------------------------------------
 // Blocked (recursive) routines
 // ------------------------------------------------------------------------------------------
-static inline int split_n1(int n) {
-    int nblk = (n + DB - 1) / DB;
-    return ((nblk + 1) / 2) * DB;
+static inline int split_n1(int n, int gran = DB) {
+    int nblk = (n + gran - 1) / gran;
+    return ((nblk + 1) / 2) * gran;
 }
 
 template <class T> static Operand<T> op_inv(const T* inv, int trans, int conj) {
@@ -920,53 +920,148 @@ template <class T> static Operand<T> op_inv(const T* inv, int trans, int conj) {
     return o;
 }
 
-template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
-    if (n <= 0 || m <= 0) return;
-    const T* invU = c.scratch<T>("invU", 0);
-    if (n <= DB) {
-        Epi e; e.inplace = 1;
-        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
-                Tr<T>::zero(), X, ldx, e);
-        return;
+// ---- merged 256x256 inverse diagonal blocks (solves outside potrf) --------------------------------------------
+// The solves recurse down to inverted diagonal blocks.  With 64x64 blocks a triangular solve of order 2048 is 63
+// launches, half of them 64-row products that fill a quarter of the chip for ~14 us each (30 % of hegst's time at
+// C3).  After the factorization the 64-block inverses are merged pairwise, twice,
+//     inv([[U0, M], [0, U1]]) = [[I0, -I0 M I1], [0, I1]],
+// into inverses of the 256x256 diagonal blocks (two small launches for the whole matrix); the solves then stop
+// at 256 (15 launches for order 2048).  Same flops: the inverse is used through its stored triangle only.
+constexpr int BB = 256;
+
+template <class T> __global__ void __launch_bounds__(256) place_inv64_kernel(int nblk64, const T* inv64, T* inv256) {
+    const int b = blockIdx.x;                 // 64-block slot, 4 per 256-group
+    T* G = inv256 + (size_t)(b / 4) * BB * BB + (size_t)(b % 4) * DB * (1 + BB);
+    for (int e = threadIdx.x; e < DB * DB; e += 256) {
+        const int r = e % DB, cc = e / DB;
+        T v = (r == cc) ? Tr<T>::one() : Tr<T>::zero();
+        if (b < nblk64) v = inv64[(size_t)b * DB * DB + e];
+        G[(size_t)r + (size_t)cc * BB] = v;
     }
-    int n1 = split_n1(n), n2 = n - n1;
-    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx);
-    gemm<T>(c, st, n1, m, n2, Tr<T>::make(-1.0, 0.0), opA('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
-            opB('N', X + n1, ldx), Tr<T>::one(), X, ldx);
-    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx);
 }
 
-template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
+// P = -L M R for one s x s off-diagonal block of every 256-group (s = 64: blocks (0,1) and (2,3); s = 128: block
+// (01, 23)); L, R = the already merged inverse diagonal blocks (upper triangular), M from U.  One workgroup per
+// 32-column panel of P; Y = M R[:, panel] goes through LDS.
+template <class T> __global__ void __launch_bounds__(256) tri_merge_kernel(int s, T* inv256, const T* U, int ldu, int N) {
+    __shared__ T Y[32][129];   // Y[c][r]
+    const int g = blockIdx.y, pc = blockIdx.x, z = blockIdx.z;
+    const int r0 = (s == 64) ? z * 128 : 0, c0 = r0 + s;
+    T* G = inv256 + (size_t)g * BB * BB;
+    const int k0 = g * BB;
+    const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5;
+    const int cc = pc * 32 + c;   // column inside the s-block
+    for (int j = 0; j < s / 8; ++j) {
+        const int r = rg + 8 * j;
+        const int gr = k0 + r0 + r;
+        T acc = Tr<T>::zero();
+        if (gr < N)
+            for (int pp = 0; pp <= cc; ++pp) {
+                const int gc = k0 + c0 + pp;
+                if (gc >= N) break;
+                fma_(acc, U[(size_t)gr + (size_t)gc * ldu], G[(size_t)(c0 + pp) + (size_t)(c0 + cc) * BB]);
+            }
+        Y[c][r] = acc;
+    }
+    __syncthreads();
+    for (int j = 0; j < s / 8; ++j) {
+        const int r = rg + 8 * j;
+        T acc = Tr<T>::zero();
+        for (int pp = r; pp < s; ++pp) fma_(acc, G[(size_t)(r0 + r) + (size_t)(r0 + pp) * BB], Y[c][pp]);
+        G[(size_t)(r0 + r) + (size_t)(c0 + cc) * BB] = -acc;
+    }
+}
+
+template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
+    const int nblk64 = (N + DB - 1) / DB, ng = (N + BB - 1) / BB;
+    if (ng <= 0) return;
+    const T* inv64 = c.scratch<T>("invU", 0);
+    T* inv256 = c.scratch<T>("invU256", (size_t)ng * BB * BB);
+    EIG_HIP(hipMemsetAsync(inv256, 0, sizeof(T) * (size_t)ng * BB * BB, st));
+    hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256);
+    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N);
+    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N);
+    EIG_HIP(hipGetLastError());
+}
+
+template <class T> static Operand<T> op_inv256(Ctx& c, int k0, int trans, int conj) {
+    Operand<T> o;
+    o.p = c.scratch<T>("invU256", 0) + (size_t)(k0 / BB) * BB * BB; o.ld = BB; o.trans = trans; o.conj = conj; o.mask = M_UPPER;
+    return o;
+}
+// result of a 256-base product goes through scratch (row blocks of the result are other workgroups' operands)
+template <class T> static void copy_back(hipStream_t st, const T* tmp, int ldt, T* X, int ldx, int rows, int cols) {
+    EIG_HIP(hipMemcpy2DAsync(X, sizeof(T) * ldx, tmp, sizeof(T) * ldt, sizeof(T) * rows, cols, hipMemcpyDeviceToDevice, st));
+}
+
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
-    if (n <= DB) {
-        Epi e; e.inplace = 1;
-        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
-                Tr<T>::zero(), X, ldx, e);
+    if (base != BB) base = DB;
+    if (n <= base) {
+        if (base == DB) {
+            Epi e; e.inplace = 1;
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
+                    Tr<T>::zero(), X, ldx, e);
+        } else {
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv256<T>(c, k0, 0, 0), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
+            copy_back(st, tmp, n, X, ldx, n, m);
+        }
         return;
     }
-    int n1 = split_n1(n), n2 = n - n1;
-    trsm_LUC(c, st, n1, m, U, ldu, k0, X, ldx);
+    int n1 = split_n1(n, base), n2 = n - n1;
+    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, base);
+    gemm<T>(c, st, n1, m, n2, Tr<T>::make(-1.0, 0.0), opA('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
+            opB('N', X + n1, ldx), Tr<T>::one(), X, ldx);
+    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx, base);
+}
+
+template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
+    if (n <= 0 || m <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (base != BB) base = DB;
+    if (n <= base) {
+        if (base == DB) {
+            Epi e; e.inplace = 1;
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
+                    Tr<T>::zero(), X, ldx, e);
+        } else {
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv256<T>(c, k0, 1, 1), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
+            copy_back(st, tmp, n, X, ldx, n, m);
+        }
+        return;
+    }
+    int n1 = split_n1(n, base), n2 = n - n1;
+    trsm_LUC(c, st, n1, m, U, ldu, k0, X, ldx, base);
     gemm<T>(c, st, n2, m, n1, Tr<T>::make(-1.0, 0.0), opA('C', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
             opB('N', X, ldx), Tr<T>::one(), X + n1, ldx);
-    trsm_LUC(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx);
+    trsm_LUC(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, base);
 }
 
 // X is m x n (m rows), solve X <- X U^-1 with U = U(k0:k0+n, k0:k0+n)
-template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx) {
+template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
-    if (n <= DB) {
-        Epi e; e.inplace = 2;
-        gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
-                Tr<T>::zero(), X, ldx, e);
+    if (base != BB) base = DB;
+    if (n <= base) {
+        if (base == DB) {
+            Epi e; e.inplace = 2;
+            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
+                    Tr<T>::zero(), X, ldx, e);
+        } else {
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
+            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv256<T>(c, k0, 1, 0), Tr<T>::zero(), tmp, m);
+            copy_back(st, tmp, m, X, ldx, m, n);
+        }
         return;
     }
-    int n1 = split_n1(n), n2 = n - n1;
-    trsm_RUN(c, st, n1, m, U, ldu, k0, X, ldx);
+    int n1 = split_n1(n, base), n2 = n - n1;
+    trsm_RUN(c, st, n1, m, U, ldu, k0, X, ldx, base);
     gemm<T>(c, st, m, n2, n1, Tr<T>::make(-1.0, 0.0), opA('N', X, ldx),
             opB('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu), Tr<T>::one(), X + (size_t)n1 * ldx, ldx);
-    trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx);
+    trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx, base);
 }
 
 template <class T> static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU) {
@@ -1100,8 +1195,8 @@ template <class T> static void hegst_two_solves_at(Ctx& c, hipStream_t st, int N
     T* F = c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", (size_t)N * N);
     const int nb32 = (N + 31) / 32;
     hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)Ablk, lda, F, N);
-    trsm_LUC(c, st, N, N, U, ldu, k0, F, N);   // F <- U(k0.., k0..)^-H F
-    trsm_RUN(c, st, N, N, U, ldu, k0, F, N);   // F <- F U(k0.., k0..)^-1
+    trsm_LUC(c, st, N, N, U, ldu, k0, F, N, c.trsm_base);   // F <- U(k0.., k0..)^-H F
+    trsm_RUN(c, st, N, N, U, ldu, k0, F, N, c.trsm_base);   // F <- F U(k0.., k0..)^-1
     size_t tot = (size_t)N * N;
     hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, Ablk, lda);
     EIG_HIP(hipGetLastError());
@@ -1118,14 +1213,14 @@ template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k
         hegst_two_solves_at(c, st, n, k0, A, lda, U, ldu);
         return;
     }
-    int n1 = split_n1(n), n2 = n - n1;
+    int n1 = split_n1(n, c.trsm_base), n2 = n - n1;   // block boundaries must match the inverse diagonal blocks
     hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr);
     T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
     T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
     T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
     const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
     const T mhalf = Tr<T>::make(-0.5, 0.0);
-    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda);                     // A12 <- U11^-H A12
+    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda, c.trsm_base);        // A12 <- U11^-H A12
     // Herm(A11) completed once into scratch: the two hemm steps are then plain full-rate gemms
     T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
     {
@@ -1144,7 +1239,7 @@ template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k
         gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
     }
     hemm_half();
-    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda);               // A12 <- A12 U22^-1
+    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda, c.trsm_base);  // A12 <- A12 U22^-1
     hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr);
 }
 
@@ -1214,9 +1309,10 @@ template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* 
     template void her2k_un<T>(Ctx&, hipStream_t, int, int, const T*, int, const T*, int, T*, int);                       \
     template void potrf_upper<T>(Ctx&, hipStream_t, int, T*, int);                                                       \
     template void build_invU<T>(Ctx&, hipStream_t, int, const T*, int);                                                  \
-    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
-    template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
-    template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int);                                 \
+    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
+    template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
+    template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
+    template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \
     template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \
     template void potrf_hegst_overlapped<T>(Ctx&, int, T*, int, T*, int);
 INST(double)

@@ -105,6 +105,9 @@ constexpr int kOverlapDefault = 0;
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
 constexpr int kGstModeDefault = 2;
 constexpr int kGstThrDefault = 2048;
+// Order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64 (as produced by the
+// factorization) or 256 (merged after it, build_inv256 in blas3.hip)
+constexpr int kTrsmBaseDefault = 256;
 
 struct Ctx {
     int dev = -1;
@@ -133,6 +136,7 @@ struct Ctx {
         const void* ptrs[16] = {};
     };
     std::map<std::string, GraphEntry> graphs;
+    int trsm_base = kTrsmBaseDefault;
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer

@@ -345,6 +345,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
             return -1;
         }
         pt.begin(PH_GST);
+        if (c.trsm_base == 256) build_inv256<T>(c, st, N, (const T*)B, ldb);   // for the final trsm
         pt.end(PH_GST);
     } else {
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
@@ -361,6 +362,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     // The reference saves strict-lower(A) in Z here and restores it later (:144-152) because
     // its gst/td2 overwrite parts of it; this implementation never writes below the diagonal.
     pt.begin(PH_GST);
+    if (c.trsm_base == 256) build_inv256<T>(c, st, N, (const T*)B, ldb);
     hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
     pt.end(PH_GST);
     }
@@ -368,7 +370,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
                              liwork);  // :163
     if (info != 0) return -1;
     pt.begin(PH_TRSM);
-    trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz);  // :169
+    trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz, c.trsm_base);  // :169
     pt.end(PH_TRSM);
     pt.begin(PH_D2H);
     if (!skip_host_copy) {
@@ -514,6 +516,7 @@ int eigsolve_zhegst(int N, void* A_d, int lda, const void* B_d, int ldb, int nb)
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
+        if (c.trsm_base == 256) build_inv256<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
         hegst_upper<cplx>(c, c.s1, N, (cplx*)A_d, lda, (const cplx*)B_d, ldb);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;
@@ -524,6 +527,7 @@ int eigsolve_dsygst(int N, double* A_d, int lda, const double* B_d, int ldb, int
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<double>(c, c.s1, N, B_d, ldb);
+        if (c.trsm_base == 256) build_inv256<double>(c, c.s1, N, B_d, ldb);
         hegst_upper<double>(c, c.s1, N, A_d, lda, B_d, ldb);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;
@@ -656,7 +660,8 @@ template <class T> static int trsm_entry(int N, int m, const T* U, int ldu, T* Z
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<T>(c, c.s1, N, U, ldu);
-        trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz);
+        if (c.trsm_base == 256) build_inv256<T>(c, c.s1, N, U, ldu);
+        trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz, c.trsm_base);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;
     });

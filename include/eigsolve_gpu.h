@@ -39,7 +39,7 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr"};
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base"};
  * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
@@ -52,6 +52,8 @@ int eigsolve_set_host_threads(int nthreads);
  * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
  * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
  * larger than "gst_thr" (default 2048), two solves below.
+ * "trsm_base": order of the inverted diagonal blocks the triangular solves outside potrf stop at, 64 or 256 (default:
+ * the 64-block inverses of the factorization merged into 256-block inverses, 4x fewer launches per solve).
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

@@ -510,9 +510,10 @@ def test_heevd_standard_problem(env, cplx, n, il, iu, tri):
 
 @pytest.mark.parametrize("cplx", [False, True])
 def test_algorithm_options_agree(env, cplx):
-    """The three forms of the reduction to standard form (symmetric recursion / two full solves / hybrid) and the two
-    back-transformation block widths (64 = the reference's larfb width, 128 = merged T factors) are the same
-    mathematics: results agree to rounding, each is bit-reproducible."""
+    """The three forms of the reduction to standard form (symmetric recursion / two full solves / hybrid), the two
+    back-transformation block widths (64 = the reference's larfb width, 128 = merged T factors) and the two orders of
+    the inverted diagonal blocks in the triangular solves (64 / merged 256) are the same mathematics: results agree to
+    rounding."""
     torch, oracle, api = env
     n, m = 700, 180
     A = oracle.gen_spd_fast(n, 4100 + n, cplx)
@@ -520,7 +521,8 @@ def test_algorithm_options_agree(env, cplx):
     res = {}
     try:
         for key, opts in (("default", {}), ("gst0", {"gst": 0}), ("gst1", {"gst": 1}), ("gst2", {"gst": 2, "gst_thr": 256}),
-                          ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128})):
+                          ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128}), ("tb64", {"trsm_base": 64}),
+                          ("tb256_gst2", {"trsm_base": 256, "gst": 2, "gst_thr": 256})):
             for k, v in opts.items():
                 assert api.set_option(k, v) == 0
             info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
@@ -530,7 +532,7 @@ def test_algorithm_options_agree(env, cplx):
             for k in opts:
                 api.set_option(k, -1 if k == "gst" else 0)
     finally:
-        for k in ("gst", "gst_thr", "bt_nb"):
+        for k in ("gst", "gst_thr", "bt_nb", "trsm_base"):
             api.set_option(k, -1 if k == "gst" else 0)
     w0, Z0 = res["default"]
     for key, (w, Z) in res.items():
