@@ -929,8 +929,8 @@ template <class T> static Operand<T> op_inv(const T* inv, int trans, int conj) {
 // at 256 (15 launches for order 2048).  Same flops: the inverse is used through its stored triangle only.
 constexpr int BB = 256;
 
-template <class T> __global__ void __launch_bounds__(256) place_inv64_kernel(int nblk64, const T* inv64, T* inv256) {
-    const int b = blockIdx.x;                 // 64-block slot, 4 per 256-group
+template <class T> __global__ void __launch_bounds__(256) place_inv64_kernel(int nblk64, const T* inv64, T* inv256, int g0) {
+    const int b = g0 * 4 + blockIdx.x;        // 64-block slot, 4 per 256-group
     T* G = inv256 + (size_t)(b / 4) * BB * BB + (size_t)(b % 4) * DB * (1 + BB);
     for (int e = threadIdx.x; e < DB * DB; e += 256) {
         const int r = e % DB, cc = e / DB;
@@ -943,45 +943,65 @@ template <class T> __global__ void __launch_bounds__(256) place_inv64_kernel(int
 // P = -L M R for one s x s off-diagonal block of every 256-group (s = 64: blocks (0,1) and (2,3); s = 128: block
 // (01, 23)); L, R = the already merged inverse diagonal blocks (upper triangular), M from U.  One workgroup per
 // 32-column panel of P; Y = M R[:, panel] goes through LDS.
-template <class T> __global__ void __launch_bounds__(256) tri_merge_kernel(int s, T* inv256, const T* U, int ldu, int N) {
-    __shared__ T Y[32][129];   // Y[c][r]
-    const int g = blockIdx.y, pc = blockIdx.x, z = blockIdx.z;
+template <class T> __global__ void __launch_bounds__(256) tri_merge_kernel(int s, T* inv256, const T* U, int ldu, int N, int g0) {
+    __shared__ T Ps[128][33];   // R panel, then the Y panel: [p][c]
+    const int g = g0 + blockIdx.y, pc = blockIdx.x, z = blockIdx.z;
     const int r0 = (s == 64) ? z * 128 : 0, c0 = r0 + s;
     T* G = inv256 + (size_t)g * BB * BB;
     const int k0 = g * BB;
-    const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5;
-    const int cc = pc * 32 + c;   // column inside the s-block
-    for (int j = 0; j < s / 8; ++j) {
-        const int r = rg + 8 * j;
-        const int gr = k0 + r0 + r;
-        T acc = Tr<T>::zero();
-        if (gr < N)
-            for (int pp = 0; pp <= cc; ++pp) {
-                const int gc = k0 + c0 + pp;
-                if (gc >= N) break;
-                fma_(acc, U[(size_t)gr + (size_t)gc * ldu], G[(size_t)(c0 + pp) + (size_t)(c0 + cc) * BB]);
-            }
-        Y[c][r] = acc;
+    const int tid = threadIdx.x;
+    // one lane per row (coalesced column loads of M and L), 256/s column slices of the 32-column panel
+    const int r = tid % s, part = tid / s, cw = 32 / (256 / s), cb = part * cw;
+    for (int e = tid; e < s * 32; e += 256) {
+        const int pp = e % s, cc = e / s;
+        Ps[pp][cc] = G[(size_t)(c0 + pp) + (size_t)(c0 + pc * 32 + cc) * BB];   // zero below the diagonal (memset)
     }
     __syncthreads();
-    for (int j = 0; j < s / 8; ++j) {
-        const int r = rg + 8 * j;
-        T acc = Tr<T>::zero();
-        for (int pp = r; pp < s; ++pp) fma_(acc, G[(size_t)(r0 + r) + (size_t)(r0 + pp) * BB], Y[c][pp]);
-        G[(size_t)(r0 + r) + (size_t)(c0 + cc) * BB] = -acc;
+    T acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = Tr<T>::zero();
+    const int gr = k0 + r0 + r;
+    const int pend = min(s, pc * 32 + 32);   // R is upper triangular: rows beyond the panel's last column are zero
+#pragma unroll 4
+    for (int pp = 0; pp < pend; ++pp) {
+        const int gc = k0 + c0 + pp;
+        const bool ok = gr < N && gc < N;
+        const T mv = sel(ok, U[(size_t)min(gr, N - 1) + (size_t)min(gc, N - 1) * ldu], Tr<T>::zero());
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < cw) fma_(acc[q], mv, Ps[pp][cb + q]);
     }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < cw) { Ps[r][cb + q] = acc[q]; acc[q] = Tr<T>::zero(); }
+    __syncthreads();
+#pragma unroll 4
+    for (int pp = 0; pp < s; ++pp) {
+        const T lv = G[(size_t)(r0 + r) + (size_t)(r0 + pp) * BB];   // zero for pp < r
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < cw) fma_(acc[q], lv, Ps[pp][cb + q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        if (q < cw) G[(size_t)(r0 + r) + (size_t)(c0 + pc * 32 + cb + q) * BB] = -acc[q];
 }
 
-template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
-    const int nblk64 = (N + DB - 1) / DB, ng = (N + BB - 1) / BB;
+// groups g0 .. g0+ng-1 (their 64-block inverses must be complete)
+template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N, const T* U, int ldu, int g0, int ng) {
+    const int nblk64 = (N + DB - 1) / DB, ngall = (N + BB - 1) / BB;
     if (ng <= 0) return;
     const T* inv64 = c.scratch<T>("invU", 0);
-    T* inv256 = c.scratch<T>("invU256", (size_t)ng * BB * BB);
-    EIG_HIP(hipMemsetAsync(inv256, 0, sizeof(T) * (size_t)ng * BB * BB, st));
-    hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256);
-    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N);
-    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N);
+    T* inv256 = c.scratch<T>("invU256", (size_t)ngall * BB * BB);
+    EIG_HIP(hipMemsetAsync(inv256 + (size_t)g0 * BB * BB, 0, sizeof(T) * (size_t)ng * BB * BB, st));
+    hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256, g0);
+    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N, g0);
+    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N, g0);
     EIG_HIP(hipGetLastError());
+}
+template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
+    build_inv256_groups(c, st, N, U, ldu, 0, (N + BB - 1) / BB);
 }
 
 template <class T> static Operand<T> op_inv256(Ctx& c, int k0, int trans, int conj) {
@@ -1064,29 +1084,38 @@ template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* 
     trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx, base);
 }
 
-template <class T> static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU) {
+// use256: block boundaries above 256 fall on multiples of 256, every finished 256-block gets its merged inverse at
+// once (3 small launches) and the panel solves of the larger levels stop at it.
+template <class T>
+static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU, bool use256 = false, bool block_root = false) {
     if (n <= 0) return;
     if (n <= DB) {
         hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(256), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info);
         EIG_HIP(hipGetLastError());
+        if (use256 && block_root) build_inv256_groups<T>(c, st, Ntot, (const T*)B, ldb, k0 / BB, 1);
         return;
     }
-    int n1 = split_n1(n), n2 = n - n1;
-    potrf_rec(c, st, Ntot, n1, k0, B, ldb, invU);
+    const bool big = use256 && n > BB;
+    int n1 = split_n1(n, big ? BB : DB), n2 = n - n1;
+    potrf_rec(c, st, Ntot, n1, k0, B, ldb, invU, use256, big && n1 <= BB);
     T* B12 = B + (size_t)k0 + (size_t)(k0 + n1) * ldb;
     T* B22 = B + (size_t)(k0 + n1) + (size_t)(k0 + n1) * ldb;
-    trsm_LUC(c, st, n1, n2, B, ldb, k0, B12, ldb);
+    trsm_LUC(c, st, n1, n2, B, ldb, k0, B12, ldb, big ? BB : DB);
     Epi e; e.uplo = 1; e.herm_diag = 1;
     gemm<T>(c, st, n2, n2, n1, Tr<T>::make(-1.0, 0.0), opA('C', (const T*)B12, ldb), opB('N', (const T*)B12, ldb),
             Tr<T>::one(), B22, ldb, e);
-    potrf_rec(c, st, Ntot, n2, k0 + n1, B, ldb, invU);
+    potrf_rec(c, st, Ntot, n2, k0 + n1, B, ldb, invU, use256, big && n2 <= BB);
+    if (use256 && block_root) build_inv256_groups<T>(c, st, Ntot, (const T*)B, ldb, k0 / BB, 1);
 }
 
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
     EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), st));
+    // (merging the inverses block by block inside the recursion was measured: the three small launches per
+    //  256-block sit on the factorization's critical path and cost more than the panel solves gain)
     potrf_rec(c, st, N, N, 0, B, ldb, invU);
+    if (c.trsm_base == BB) build_inv256<T>(c, st, N, (const T*)B, ldb);
 }
 
 template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {

@@ -361,8 +361,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     }
     // The reference saves strict-lower(A) in Z here and restores it later (:144-152) because
     // its gst/td2 overwrite parts of it; this implementation never writes below the diagonal.
-    pt.begin(PH_GST);
-    if (c.trsm_base == 256) build_inv256<T>(c, st, N, (const T*)B, ldb);
+    pt.begin(PH_GST);   // (potrf_upper has merged the inverse diagonal blocks already)
     hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
     pt.end(PH_GST);
     }
