@@ -694,37 +694,41 @@ template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* 
 // ------------------------------------------------------------------------------------------
 constexpr int DB = kDiagBlk;
 constexpr int DBL = DB + 1;  // LDS leading dimension
+constexpr int PB = 2;            // diag_block_kernel: each thread owns a PB x PB block ...
+constexpr int NTD = DB / PB;     // ... of the 64x64 matrix: NTD x NTD threads
+constexpr int DGT = NTD * NTD;   // = 1024: four waves per SIMD, to overlap the 11-cycle latency of dependent fp64 FMAs
 
 // 64x64 upper Cholesky (optional) followed by the inverse of the factor, one workgroup.
-// Register-resident: thread (tr, tc) = (tid/16, tid%16) owns the 4x4 block rows 4tr.., cols 4tc..
-// of U (and of X = U^-1).  Each of the 64 elimination steps broadcasts one row (and for the inverse
+// Register-resident: thread (tr, tc) = (tid/NTD, tid%NTD) owns the PB x PB block rows PB*tr.., cols PB*tc..
+// of U (and of X = U^-1); PB = 2 -> 1024 threads = four waves per SIMD (a dependent fp64 FMA has 11 cycles of latency
+// against 4 of issue, and the elimination is one long dependency chain: one wave per SIMD leaves the pipe idle).  Each of the 64 elimination steps broadcasts one row (and for the inverse
 // one column) through a double-buffered LDS line and costs a single barrier.  The step loops are
-// unrolled over the position inside the 4x4 block so that every register index is static; the pivot
+// unrolled over the position inside the PB x PB block so that every register index is static; the pivot
 // is a Newton-refined v_rsq_f64 (no IEEE sqrt / division on the 64-step chain) and its reciprocal is
 // kept for the inversion, which then has no division at all.  This kernel sits on the critical path
 // of potrf N/64 times.
 //   do_chol = 1: block <- chol(block) (upper), written back; info <- first bad pivot (1-based, global)
 //   inverse written to invU (DB x DB, ld DB, identity-padded, zero below the diagonal).
 template <class T>
-__global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, int ldu, T* invU, int do_chol, int k0_single,
+__global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, int ldu, T* invU, int do_chol, int k0_single,
                                                          int* info) {
     __shared__ T rowb[2][DB];
     __shared__ T colb[2][DB];
     __shared__ T dinvs[DB];   // reciprocals of the diagonal of U
     const int tid = threadIdx.x;
-    const int tr = tid >> 4, tc = tid & 15;
+    const int tr = tid / NTD, tc = tid % NTD;
     const int blk = (k0_single >= 0) ? k0_single / DB : blockIdx.x;
     const int k0 = blk * DB;
     const int nb = min(DB, n_total - k0);
     T* Ublk = Umat + (size_t)k0 + (size_t)k0 * ldu;
     T* inv = invU + (size_t)blk * DB * DB;
 
-    T u[4][4], x[4][4];
+    T u[PB][PB], x[PB][PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < PB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int r = 4 * tr + i, cc = 4 * tc + j;
+        for (int j = 0; j < PB; ++j) {
+            int r = PB * tr + i, cc = PB * tc + j;
             const bool in = r < nb && cc < nb && r <= cc;
             T v = Ublk[(size_t)min(r, nb - 1) + (size_t)min(cc, nb - 1) * ldu];
             u[i][j] = sel(in, v, sel(r == cc, Tr<T>::one(), Tr<T>::zero()));
@@ -734,13 +738,13 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
     const bool upper_blk = tc >= tr;   // only blocks on or above the block diagonal carry data
     const bool diag_blk = tc == tr;
     if (do_chol) {
-        for (int jb = 0; jb < DB / 4; ++jb) {
+        for (int jb = 0; jb < DB / PB; ++jb) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = 4 * jb + jj, buf = jj & 1;
+            for (int jj = 0; jj < PB; ++jj) {
+                const int j = PB * jb + jj, buf = jj & 1;
                 if (tr == jb) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = u[jj][q];
+                    for (int q = 0; q < PB; ++q) rowb[buf][PB * tc + q] = u[jj][q];
                 }
                 __syncthreads();
                 double d = real_(rowb[buf][j]);
@@ -752,17 +756,17 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                     const double ipiv = fast_rsqrt(d);
                     double piv = d * ipiv;
                     piv = fma(fma(-piv, piv, d), 0.5 * ipiv, piv);
-                    T uc[4], ur[4];
+                    T uc[PB], ur[PB];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uc[q] = rowb[buf][4 * tc + q] * ipiv;   // u(j, c) for my columns
-                        ur[q] = rowb[buf][4 * tr + q] * ipiv;   // u(j, r) for my rows
+                    for (int q = 0; q < PB; ++q) {
+                        uc[q] = rowb[buf][PB * tc + q] * ipiv;   // u(j, c) for my columns
+                        ur[q] = rowb[buf][PB * tr + q] * ipiv;   // u(j, r) for my rows
                     }
                     if (tr > jb) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < PB; ++i)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < PB; ++q) {
                                 T t = Tr<T>::zero();
                                 fmac_(t, ur[i], uc[q]);
                                 u[i][q] = u[i][q] - t;    // (entries below the diagonal of a diagonal block are never read)
@@ -770,14 +774,14 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
                     } else {
                         if (diag_blk) dinvs[j] = Tr<T>::make(ipiv, 0.0);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < PB; ++q) {
                             if (!diag_blk || q > jj) u[jj][q] = uc[q];
                             else if (q == jj) u[jj][q] = Tr<T>::make(piv, 0.0);
                         }
 #pragma unroll
-                        for (int i = jj + 1; i < 4; ++i)
+                        for (int i = jj + 1; i < PB; ++i)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < PB; ++q) {
                                 T t = Tr<T>::zero();
                                 fmac_(t, ur[i], uc[q]);
                                 u[i][q] = u[i][q] - t;
@@ -787,59 +791,59 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PB; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int r = 4 * tr + i, cc = 4 * tc + q;
+            for (int q = 0; q < PB; ++q) {
+                int r = PB * tr + i, cc = PB * tc + q;
                 if (r < nb && cc < nb && r <= cc) Ublk[(size_t)r + (size_t)cc * ldu] = u[i][q];
             }
     } else if (diag_blk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PB; ++i) {
             const T dgn = u[i][i];
-            dinvs[4 * tr + i] = conj_(dgn) * (1.0 / abs2_(dgn));
+            dinvs[PB * tr + i] = conj_(dgn) * (1.0 / abs2_(dgn));
         }
     }
     __syncthreads();
 
     // X = U^-1 by right-looking back substitution on the rows, bottom up
-    for (int ib = DB / 4 - 1; ib >= 0; --ib) {
+    for (int ib = DB / PB - 1; ib >= 0; --ib) {
 #pragma unroll
-        for (int ii = 3; ii >= 0; --ii) {
-            const int i2 = 4 * ib + ii, buf = ii & 1;
+        for (int ii = PB - 1; ii >= 0; --ii) {
+            const int i2 = PB * ib + ii, buf = ii & 1;
             if (tr == ib) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) rowb[buf][4 * tc + q] = x[ii][q];
+                for (int q = 0; q < PB; ++q) rowb[buf][PB * tc + q] = x[ii][q];
             }
             if (tc == ib) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) colb[buf][4 * tr + i] = u[i][ii];
+                for (int i = 0; i < PB; ++i) colb[buf][PB * tr + i] = u[i][ii];
             }
             __syncthreads();
             if (upper_blk && tr <= ib && tc >= ib) {   // rows <= i2, columns >= i2
                 const T dinv = dinvs[i2];
-                T xr[4], uc2[4];
+                T xr[PB], uc2[PB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    xr[q] = rowb[buf][4 * tc + q] * dinv;   // final x(i2, c)   (zero for c < i2)
-                    uc2[q] = colb[buf][4 * tr + q];         // u(r, i2)
+                for (int q = 0; q < PB; ++q) {
+                    xr[q] = rowb[buf][PB * tc + q] * dinv;   // final x(i2, c)   (zero for c < i2)
+                    uc2[q] = colb[buf][PB * tr + q];         // u(r, i2)
                 }
                 if (tr < ib) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < PB; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < PB; ++q) {
                             T t = Tr<T>::zero();
                             fma_(t, uc2[i], xr[q]);
                             x[i][q] = x[i][q] - t;
                         }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) x[ii][q] = xr[q];
+                    for (int q = 0; q < PB; ++q) x[ii][q] = xr[q];
 #pragma unroll
                     for (int i = 0; i < ii; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < PB; ++q) {
                             T t = Tr<T>::zero();
                             fma_(t, uc2[i], xr[q]);
                             x[i][q] = x[i][q] - t;
@@ -849,10 +853,10 @@ __global__ void __launch_bounds__(256) diag_block_kernel(int n_total, T* Umat, i
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < PB; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int r = 4 * tr + i, cc = 4 * tc + q;
+        for (int q = 0; q < PB; ++q) {
+            int r = PB * tr + i, cc = PB * tc + q;
             inv[r + cc * DB] = (r <= cc) ? x[i][q] : Tr<T>::zero();
         }
 }
@@ -1090,7 +1094,7 @@ template <class T>
 static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU, bool use256 = false, bool block_root = false) {
     if (n <= 0) return;
     if (n <= DB) {
-        hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(256), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info);
+        hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(DGT), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info);
         EIG_HIP(hipGetLastError());
         if (use256 && block_root) build_inv256_groups<T>(c, st, Ntot, (const T*)B, ldb, k0 / BB, 1);
         return;
@@ -1122,7 +1126,7 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
     int nblk = (N + DB - 1) / DB;
     if (nblk <= 0) return;
     T* invU = c.scratch<T>("invU", (size_t)nblk * DB * DB);
-    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nblk), dim3(256), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1,
+    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nblk), dim3(DGT), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1,
                        c.d_info);
     EIG_HIP(hipGetLastError());
 }
