@@ -1182,7 +1182,7 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     //               1 = two full triangular solves (N^3 multiply-adds, ~4N/64 large launches),
     //               2 = hybrid (default): the symmetric algorithm (zhegst_gpu.F90:51-107) on the large levels, where
     //                   every operation is a chip-filling MFMA launch, two solves on diagonal blocks of order
-    //                   <= EIGSOLVE_GST_THR (2048).  C3 (N=4096): 28.3 / 14.2 / 13.3 ms, batch 11.9 -> 12.4 problems/s.
+    //                   <= EIGSOLVE_GST_THR (1024).  C3 (N=4096): 28.3 / 14.2 / 11.0 ms with the 256-block inverses.
     const int mode = c.gst_mode, thr = c.gst_thr;   // EIGSOLVE_GST / EIGSOLVE_GST_THR, eigsolve_set_option("gst" / "gst_thr")
     if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
     else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);

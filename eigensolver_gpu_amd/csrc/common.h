@@ -104,7 +104,7 @@ constexpr int kOverlapDefault = 0;
 // Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
 constexpr int kGstModeDefault = 2;
-constexpr int kGstThrDefault = 2048;
+constexpr int kGstThrDefault = 1024;
 // Order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64 (as produced by the
 // factorization) or 256 (merged after it, build_inv256 in blas3.hip)
 constexpr int kTrsmBaseDefault = 256;

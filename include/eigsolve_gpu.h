@@ -51,7 +51,7 @@ int eigsolve_set_host_threads(int nthreads);
  * "bt_nb": 64 (the reference's larfb width) or 128 (default: two 64-blocks with a merged T factor).
  * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
  * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
- * larger than "gst_thr" (default 2048), two solves below.
+ * larger than "gst_thr" (default 1024), two solves below.
  * "trsm_base": order of the inverted diagonal blocks the triangular solves outside potrf stop at, 64 or 256 (default:
  * the 64-block inverses of the factorization merged into 256-block inverses, 4x fewer launches per solve).
  * Returns 0 / -1 (unknown name). */
