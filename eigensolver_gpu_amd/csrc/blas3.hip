@@ -603,7 +603,10 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
         else launch_gemm<T, 32, 32>(st, g, splits);
     } else {
         long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
-        if (tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
+        // 128x128 real tiles measured slower than 64x64 on this part (dgemm 4096^3: 35.1 vs 40.8 TFLOP/s; dsygvdx
+        // N=8192: 306 vs 294 ms): kept for experiments only (EIGSOLVE_GEMM_128=1)
+        static const bool use128 = getenv("EIGSOLVE_GEMM_128") != nullptr;
+        if (use128 && tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
         else if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
         else launch_gemm<T, 32, 32>(st, g, splits);
     }
