@@ -606,7 +606,14 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
         // 128x128 real tiles measured slower than 64x64 on this part (dgemm 4096^3: 35.1 vs 40.8 TFLOP/s; dsygvdx
         // N=8192: 306 vs 294 ms): kept for experiments only (EIGSOLVE_GEMM_128=1)
         static const bool use128 = getenv("EIGSOLVE_GEMM_128") != nullptr;
+        // 128x64 tiles (each wave 64x32: 40 % fewer LDS fragment reads per MFMA than 32x32, still 2 workgroups per CU):
+        // dgemm 4096^3 40.8 -> 43.3 TFLOP/s, but inside the solver (triangular and mid-size shapes) 64x64 wins
+        // (dsygvdx N=8192: 294 vs 301 ms), so off by default.  The real engine is LDS-read bound (3.0 LDS-active
+        // cycles per MFMA against 1.5 for complex, where one fragment pair feeds four MFMAs).
+        static const bool use12864 = getenv("EIGSOLVE_GEMM_12864") != nullptr;
+        long tiles12864 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * splits;
         if (use128 && tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
+        else if (use12864 && tiles12864 >= 2L * c.n_cu) launch_gemm<T, 128, 64>(st, g, splits);
         else if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
         else launch_gemm<T, 32, 32>(st, g, splits);
     }
