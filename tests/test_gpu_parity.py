@@ -540,6 +540,19 @@ def test_algorithm_options_agree(env, cplx):
         assert oracle.compare_abs2d(Z0, Z)[0] <= 1e-9, key
 
 
+def test_randomised_sizes_ranges_and_options(env):
+    """tools/stress.py in small: random orders (block-boundary values over-represented), types, eigenpair ranges and
+    algorithm options; every case must meet the residual / orthonormality gates (a 200-case run up to N = 3000 is
+    recorded in profiles/r01_stress_200_cases.txt)."""
+    import subprocess, sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress.py"), "24", "3", "520"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "24 cases, 0 bad" in out.stdout
+
+
 def test_order_above_8192_tail_paths(env):
     """N > 8192, odd: the tail loops of the panel kernels (more than 128 hemv stripes, more than 8 gemv chunks, more
     than 1024 norm partials), remainder panels and non-power-of-two recursion splits.  Well-conditioned family, so the

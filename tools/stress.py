@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Randomised stress run through the C ABI: sizes, types, eigenpair ranges, leading dimensions and algorithm options;
+every case must meet the residual / orthonormality gates of the parity tests.  Usage: stress.py [cases] [seed] [nmax]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import eigensolver_gpu_amd.api as api
+from oracle import pyoracle as oracle
+EPS = 2.220446049250313e-16
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 900
+rng = np.random.default_rng(seed)
+bad = 0
+t0 = time.time()
+for case in range(cases):
+    n = int(rng.choice([1, 2, 3, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 700, 769, 1000, 1025, 1500][: 25])) if rng.random() < 0.6 else int(rng.integers(1, nmax + 1))
+    n = min(n, nmax)
+    cplx = bool(rng.integers(0, 2))
+    il = int(rng.integers(1, n + 1)); iu = int(rng.integers(il, n + 1))
+    if rng.random() < 0.5: il = 1
+    m = iu - il + 1
+    opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 3)),
+            "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256])), "trd_nb": int(rng.choice([64, 32, 17]))}
+    for k, v in opts.items(): assert api.set_option(k, v) == 0
+    A = oracle.gen_spd_fast(n, 100 + case, cplx)
+    B = oracle.gen_spd_fast(n, 200 + case, cplx, shift=float(n))
+    info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), il, iu)
+    w = ws.w_h.numpy()[:n].copy(); Z = np.asfortranarray(api.to_host(ws.Z_h, n, m)).copy()
+    R = A @ Z - (B @ Z) * w[il - 1:iu]
+    res = np.linalg.norm(R) / np.linalg.norm(A)
+    orth = np.abs(Z.conj().T @ (B @ Z) - np.eye(m)).max()
+    srt = bool(np.all(np.diff(w) >= 0))
+    ok = info == 0 and res <= max(n, 4) * EPS and orth <= 1e-11 and srt and np.all(np.isfinite(Z))
+    if not ok:
+        bad += 1
+    print("%s case %3d n=%4d %s il=%4d iu=%4d %s res=%.2e orth=%.2e" % ("ok " if ok else "BAD", case, n, "z" if cplx else "d", il, iu, opts, res, orth), flush=True)
+for k in ("tridiag", "gst"): api.set_option(k, -1)
+for k in ("bt_nb", "gst_thr", "trsm_base", "trd_nb"): api.set_option(k, 0)
+print("%d cases, %d bad, %.1f s" % (cases, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
