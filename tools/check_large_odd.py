@@ -5,10 +5,19 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import eigensolver_gpu_amd.api as api
-from oracle import pyoracle as oracle
+
+
+def gen_spd(n, seed, cplx, shift=0.0):
+    """Reference recipe (test_zhegvdx.F90:41-59): Hermitian T with uniform[0,1) entries, A = T T^H (+ shift I)."""
+    r = np.random.default_rng(seed)
+    T = r.random((n, n)) + (1j * r.random((n, n)) if cplx else 0.0)
+    T = np.tril(T, -1) + np.tril(T, -1).conj().T + np.diag(r.random(n))
+    M = T @ T.conj().T
+    return M + shift * np.eye(n)
+
 N = int(sys.argv[1]); cplx = (len(sys.argv) < 3 or sys.argv[2] != "real"); m = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-A = oracle.gen_spd_fast(N, 11, cplx)
-B = oracle.gen_spd_fast(N, 12, cplx, shift=float(N))
+A = gen_spd(N, 11, cplx)
+B = gen_spd(N, 12, cplx, shift=float(N))
 Ad, Bd = api.to_device(np.triu(A)), api.to_device(np.triu(B))
 t0 = time.perf_counter()
 info, ws = api.hegvdx(Ad, Bd, 1, m)

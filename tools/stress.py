@@ -5,7 +5,16 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import eigensolver_gpu_amd.api as api
-from oracle import pyoracle as oracle
+
+
+def gen_spd(n, seed, cplx, shift=0.0):
+    """Reference recipe (test_zhegvdx.F90:41-59): Hermitian T with uniform[0,1) entries, A = T T^H (+ shift I)."""
+    r = np.random.default_rng(seed)
+    T = r.random((n, n)) + (1j * r.random((n, n)) if cplx else 0.0)
+    T = np.tril(T, -1) + np.tril(T, -1).conj().T + np.diag(r.random(n))
+    M = T @ T.conj().T
+    return M + shift * np.eye(n)
+
 EPS = 2.220446049250313e-16
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -23,8 +32,8 @@ for case in range(cases):
     opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 3)),
             "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256])), "trd_nb": int(rng.choice([64, 32, 17]))}
     for k, v in opts.items(): assert api.set_option(k, v) == 0
-    A = oracle.gen_spd_fast(n, 100 + case, cplx)
-    B = oracle.gen_spd_fast(n, 200 + case, cplx, shift=float(n))
+    A = gen_spd(n, 100 + case, cplx)
+    B = gen_spd(n, 200 + case, cplx, shift=float(n))
     info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), il, iu)
     w = ws.w_h.numpy()[:n].copy(); Z = np.asfortranarray(api.to_host(ws.Z_h, n, m)).copy()
     R = A @ Z - (B @ Z) * w[il - 1:iu]
