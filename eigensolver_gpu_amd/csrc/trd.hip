@@ -57,7 +57,6 @@ template <class T> struct PanelArgs {
     int nblkA;         // norm partials (one per row-kernel wave) produced for column i
     int gh;            // hemv workgroups used for the column being finished / generated
     int nchunk;        // gemv row chunks for that column
-    int ablate;        // debug/timing only (EIGSOLVE_ABLATE): skips parts of the row kernel, results invalid
 };
 
 // larfg scalars with the reference's scaling (zhetrd_gpu.F90:275-311: scale by max(|ar|,|ai|,xnorm), no
@@ -622,8 +621,6 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
     PanelArgs<T> a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = e; a.tau = tau;
     a.xbuf = sc.xbuf; a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp; a.NP = sc.NP; a.alphaSlot = sc.alphaSlot;
-    static const int ablate_env = getenv("EIGSOLVE_ABLATE") ? atoi(getenv("EIGSOLVE_ABLATE")) : 0;
-    a.ablate = ablate_env;
     int gh_prev = 0, nchunk_prev = 0;
     for (int i = np - 1; i >= np - nb - 1; --i) {
         const bool last = (i == np - nb - 1);  // finish-only pass for the panel's leftmost column
@@ -709,7 +706,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     PanelArgs<T> a;
     a.A = const_cast<T*>(A); a.lda = lda; a.W = nullptr; a.ldw = 0; a.np = n + 1; a.nb = 1; a.i = n;
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
-    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0; a.ablate = 0;
+    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
     a.gh = hemv_grid(c, n);
     hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(256), 0, st, a, 1, 0);
     if (gather) {
