@@ -110,6 +110,44 @@ template <class T> __device__ __forceinline__ T transpose_reduce16(T (&t)[16], i
     return out;
 }
 
+// The same reduction in two halves of 8 columns, so that only 8 per-lane partials (plus two reduced values of the
+// first half) are live at a time.  Phase 1 takes 8 partials (local columns 0..7) through the halves / rows levels
+// and leaves two values per lane: w[a] holds local column a + 2*bit4 + 4*bit5.  Phase 2 merges the two halves
+// (row_ror:8 level: bit 3 selects the half), then the half-mirror level (bit 2 selects a) and the quad sum.
+// Result: the full 64-lane sum of column transpose_col_of_lane(lane) in every lane of the quad.
+template <class T> __device__ __forceinline__ void transpose_reduce8_phase1(T (&x)[8], T& w0, T& w1) {
+    T v[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        T p = x[a], q = x[a + 4];
+        swap_halves(p, q);
+        v[a] = p + q;             // lanes 0-31: local column a, lanes 32-63: a + 4
+    }
+    {
+        T p = v[0], q = v[2];
+        swap_rows(p, q);
+        w0 = p + q;               // + 2 * (bit 4 of lane)
+    }
+    {
+        T p = v[1], q = v[3];
+        swap_rows(p, q);
+        w1 = p + q;
+    }
+}
+template <class T> __device__ __forceinline__ T transpose_reduce_phase2(T a0, T a1, T b0, T b1, int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4;
+    T z0 = sel(b3, b0, a0) + dpp_get2<DPP_ROR8, 0x3>(a0, b0);   // banks 0,1 (bit 3 clear) keep / receive the first half
+    T z1 = sel(b3, b1, a1) + dpp_get2<DPP_ROR8, 0x3>(a1, b1);
+    T out = sel(b2, z1, z0) + dpp_get2<DPP_HALF_MIRROR, 0x5>(z0, z1);   // banks 0,2 (bit 2 clear)
+    out = out + dpp_get<DPP_XOR2>(out);
+    out = out + dpp_get<DPP_XOR1>(out);
+    return out;
+}
+__device__ __forceinline__ int transpose_col_of_lane(int lane) {
+    // local column a = bit 2, + 2 * bit 4 + 4 * bit 5 inside the half, + 8 * bit 3 for the second half
+    return ((lane >> 2) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 5) & 1) + 8 * ((lane >> 3) & 1);
+}
+
 // 1/x to ~1 ulp without the IEEE division sequence (x normal, nonzero): v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);

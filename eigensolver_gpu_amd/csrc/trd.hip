@@ -42,6 +42,7 @@ __device__ unsigned long long g_trd_count[2];
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
 constexpr int NBMAX = 64;  // maximum panel width
+constexpr int MVT = 320;   // panel_mv_kernel: four streaming waves + one finishing wave
 
 template <class T> struct PanelArgs {
     T* A; int lda;
@@ -295,19 +296,25 @@ __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
 }
 
 template <class T>
-__global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain, int gg) {
+__global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelArgs<T> a, int plain, int gg) {
     const int i = a.i, n = i;  // v has n entries (rows 0..i-1), v(n-1) = 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if EIG_TRD_TIMING
     const long long T0 = __builtin_readcyclecounter();
     if (blockIdx.x == gg && threadIdx.x == 0) atomicAdd(&g_trd_count[0], 1ULL);
 #endif
-    __shared__ T redy[4][64];
-    __shared__ T redt[64];
-    __shared__ T xcs[2][HT];   // xh entries of the current / next tile's columns
+    // Five waves: 0-3 stream and multiply the tiles, wave 4 evaluates the larfg scalars (a serial chain of ~1500 cycles)
+    // while the first tile is being multiplied and finishes every tile (partial sums, S, the stored v) while the
+    // others are already on the next one.  LDS hand-over buffers are double (partials) / triple (column entries of
+    // v) buffered so that one barrier per tile is enough.  Two workgroups per CU need <= 168 VGPRs per wave (10 waves
+    // on 4 SIMDs): the column reduction runs in two halves of 8 columns to stay below that.
+    __shared__ T redy[2][4][64];
+    __shared__ T redt[2][64];
+    __shared__ T xcs[3][HT];   // xh entries of the tile columns: tile k of this workgroup uses slot k % 3
     constexpr int NPL = 16;    // norm partials per lane loaded up front (N <= 4096 without the tail loop)
     const bool is_gemv = (int)blockIdx.x < gg;
     const int hb = (int)blockIdx.x - gg;  // hemv workgroup index
+    if (is_gemv && wave == 4) return;
 
     // v = scale * xh + e_(n-1), xh = raw column with the entries >= nz zeroed.  Everything below is linear in
     // v, so the products are formed with xh (known at launch) and the larfg scalars -- the end of a chain
@@ -315,12 +322,87 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
     const int nz = plain ? n : n - 1;
     const int one_at = plain ? -1 : n - 1;
     const T zero = Tr<T>::zero();
-    auto xhat = [&](int r) -> T { return sel(r < nz, a.xbuf[min(r, max(nz - 1, 0))], zero); };
     auto unit = [&](int r) -> T { return sel(r == one_at, Tr<T>::one(), zero); };
 
-    // ---------------- scalar loads first: they are waited for first (vmcnt retires in order) ----------------
+    // ---------------- Hermitian mat-vec tiles: the four streaming waves ----------------
+    const int nt = (n + HT - 1) / HT;
+    const int ntiles = nt * (nt + 1) / 2;
+    int I = 0, J = 0, t = hb;
+    if (!is_gemv && wave < 4) {
+        T av[16], xr_raw = zero;   // raw loads of the tile in flight
+        // Issue the loads of tile t: unconditional, clamped addresses, nothing else in between (a select on a
+        // loaded value is where the compiler waits; masks are applied when the tile is consumed).  The column
+        // entries of v go first: their hand-over to LDS then waits for that one load and leaves the rest in flight.
+        // All four waves store the same 64 values (a store only one wave executes lets the compiler sink the load).
+        auto issue_tile = [&](int slot) {
+            tile_decode(t, I, J);
+            const int r0 = I * HT, c0 = J * HT, r = r0 + lane;
+            const T xc_raw = a.xbuf[min(c0 + lane, max(nz - 1, 0))];
+            xr_raw = a.xbuf[min(r, max(nz - 1, 0))];
+            const size_t roff = (size_t)min(r, n - 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, n - 1) * a.lda];
+            __builtin_amdgcn_sched_barrier(0);
+            xcs[slot][lane] = sel(c0 + lane < nz, xc_raw, zero);
+        };
+        if (t < ntiles) issue_tile(0);
+        TSTAMP(0, 0, T0);   // loads issued, xcs written
+        __syncthreads();
+        TSTAMP(0, 1, T0);
+        int k = 0;
+        while (t < ntiles) {
+            const int r0 = I * HT, c0 = J * HT;
+            const bool diag = (I == J);
+            const int r = r0 + lane;
+            const int rb = k & 1, xs = k % 3;
+            const T xr = sel(r < nz, xr_raw, zero);
+            const bool interior = !diag && r0 + HT <= n && c0 + HT <= n;
+            T yI = Tr<T>::zero();
+            // 8 columns at a time: products, then the first two levels of the column reduction
+            auto half = [&](int jb, T& w0, T& w1) {
+                T tj[8];
+                if (interior) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        fma_(yI, av[jb + j], xcs[xs][wave * 16 + jb + j]);
+                        T p = Tr<T>::zero();
+                        fmac_(p, av[jb + j], xr);
+                        tj[j] = p;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int cc = c0 + wave * 16 + jb + j;
+                        const bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
+                        const bool dg = diag && r == cc;
+                        T v = sel(ok, av[jb + j], zero);
+                        v = sel(dg, Tr<T>::realpart(v), v);
+                        fma_(yI, v, xcs[xs][wave * 16 + jb + j]);
+                        T p = Tr<T>::zero();
+                        fmac_(p, sel(dg, zero, v), xr);
+                        tj[j] = p;
+                    }
+                }
+                transpose_reduce8_phase1<T>(tj, w0, w1);
+            };
+            T wa0, wa1, wb0, wb1;
+            half(0, wa0, wa1);
+            half(8, wb0, wb1);
+            const T tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
+            TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
+            redy[rb][wave][lane] = yI;
+            if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
+            t += a.gh;
+            ++k;
+            if (t < ntiles) issue_tile(k % 3);   // next tile's loads fly while wave 4 finishes this one
+            TSTAMP(0, 4, T0);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- scalar loads (gemv waves and the finishing wave) ----------------
     // raw, unconditional (clamped) loads; selects and sums happen in scalars(), after everything is issued
-    const bool does_scalars = !plain && (is_gemv || wave == 0);
     const int nnp = plain ? 1 : a.nblkA;
     T alpha_early = zero;
     double npl[NPL];
@@ -343,13 +425,12 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
         double beta;
         T tau, scale;
         larfg_scalars<T>(ss, alpha_early, beta, tau, scale);
-        if (blockIdx.x == 0 && tid == 0) {
+        if (blockIdx.x == 0 && lane == 0 && (is_gemv ? wave == 0 : wave == 4)) {
             a.e[i - 1] = beta;
             a.tau[i - 1] = tau;
         }
         return scale;
     };
-    (void)does_scalars;
 
     if (is_gemv) {
         // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk), one item per wave
@@ -360,8 +441,8 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
         const int ch = item / (2 * npo);
         const int rem = item % (2 * npo);
         const int which = rem / npo, kk = rem % npo;
-        const int k = i + 1 + kk;
-        const T* src = which == 0 ? a.A + (size_t)k * a.lda : a.W + (size_t)(k - wbase) * a.ldw;
+        const int kcol = i + 1 + kk;
+        const T* src = which == 0 ? a.A + (size_t)kcol * a.lda : a.W + (size_t)(kcol - wbase) * a.ldw;
         const int rbeg = ch * CH;
         T s = Tr<T>::zero(), eone = Tr<T>::zero();
         T sv[8], xv[8];
@@ -385,107 +466,52 @@ __global__ void __launch_bounds__(256) panel_mv_kernel(PanelArgs<T> a, int plain
         return;
     }
 
-    // ---------------- Hermitian mat-vec tiles ----------------
-    const int nt = (n + HT - 1) / HT;
-    const int ntiles = nt * (nt + 1) / 2;
-    T av[16], xr_raw = zero, lc_raw = zero;   // raw loads of the tile in flight
-    int I = 0, J = 0, t = hb, buf = 0;
-    // Issue the loads of tile t: unconditional, clamped addresses, nothing else in between (a select on a
-    // loaded value is where the compiler waits; masks are applied when the tile is consumed).  The column
-    // entries of v go first: their hand-over to LDS then waits for that one load and leaves the rest in flight.
-    // All four waves store the same 64 values (a store only wave 0 executes lets the compiler sink the load).
-    auto issue_tile = [&](int b) {
+    // ---------------- the finishing wave (wave 4 of a mat-vec workgroup) ----------------
+    T xr_raw = zero, lc_raw = zero;
+    auto issue_mine = [&]() {
         tile_decode(t, I, J);
-        const int r0 = I * HT, c0 = J * HT, r = r0 + lane;
-        const T xc_raw = a.xbuf[min(c0 + lane, max(nz - 1, 0))];
+        const int r = I * HT + lane;
         lc_raw = a.A[(size_t)min(r, n - 1) + (size_t)(n - 1) * a.lda];   // column n-1: the e_(n-1) part of v
         xr_raw = a.xbuf[min(r, max(nz - 1, 0))];
-        const size_t roff = (size_t)min(r, n - 1);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, n - 1) * a.lda];
-        __builtin_amdgcn_sched_barrier(0);
-        xcs[b][lane] = sel(c0 + lane < nz, xc_raw, zero);
     };
-    if (t < ntiles) issue_tile(0);
-    TSTAMP(0, 0, T0);   // loads issued, xcs written
+    if (t < ntiles) issue_mine();
     __syncthreads();
-    TSTAMP(0, 1, T0);
     T scale = Tr<T>::one();
-    if (!plain && wave == 0) scale = scalars();   // under the latency of the tile loads
+    if (!plain) scale = scalars();   // while waves 0-3 multiply the first tile
     TSTAMP(0, 2, T0);
-
     T Sacc = Tr<T>::zero();
+    int k = 0;
     while (t < ntiles) {
-        const int r0 = I * HT, c0 = J * HT;
+        const int r0 = I * HT, c0 = J * HT, Ic = I, Jc = J;
         const bool diag = (I == J);
         const int r = r0 + lane;
-        const int Ic = I, Jc = J;
         const T xr = sel(r < nz, xr_raw, zero);
         T lastc = sel(!plain && J == nt - 1 && r <= n - 1, lc_raw, zero);
         lastc = sel(r == n - 1, Tr<T>::realpart(lastc), lastc);
-        T yI = Tr<T>::zero();
-        T tj[16];
-        if (!diag && r0 + HT <= n && c0 + HT <= n) {
-            // interior tile (the bulk of the bytes): no masks
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                fma_(yI, av[j], xcs[buf][wave * 16 + j]);
-                T p = Tr<T>::zero();
-                fmac_(p, av[j], xr);
-                tj[j] = p;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int cc = c0 + wave * 16 + j;
-                const bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
-                const bool dg = diag && r == cc;
-                T v = sel(ok, av[j], zero);
-                v = sel(dg, Tr<T>::realpart(v), v);
-                fma_(yI, v, xcs[buf][wave * 16 + j]);
-                T p = Tr<T>::zero();
-                fmac_(p, sel(dg, zero, v), xr);
-                tj[j] = p;
-            }
-        }
-        T tval = transpose_reduce16<T>(tj, lane);
-        TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
-        redy[wave][lane] = yI;
-        if ((lane & 3) == 0) redt[wave * 16 + (lane >> 2)] = tval;
         t += a.gh;
-#if EIG_MV_PREFETCH
-        if (t < ntiles) issue_tile(buf ^ 1);   // next tile's loads fly while the barriers drain
-#endif
-        __syncthreads();
-        if (wave == 0) {
-            T yv = scale * ((redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane])) + lastc;
-            T tv = scale * redt[lane];
-            T vI = scale * xr + unit(r0 + lane);
-            T vJ = scale * xcs[buf][lane] + unit(c0 + lane);
-            if (diag) {
-                T s = yv + tv;
-                a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
-                fmac_(Sacc, vI, s);
-                if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
-            } else {
-                a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
-                a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
-                fmac_(Sacc, vI, yv);
-                fmac_(Sacc, vJ, tv);
-            }
+        if (t < ntiles) issue_mine();
+        __syncthreads();   // partial sums of tile k are in redy / redt [k & 1]
+        const int rb = k & 1, xs = k % 3;
+        T yv = scale * ((redy[rb][0][lane] + redy[rb][1][lane]) + (redy[rb][2][lane] + redy[rb][3][lane])) + lastc;
+        T tv = scale * redt[rb][lane];
+        T vI = scale * xr + unit(r0 + lane);
+        T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
+        if (diag) {
+            T s = yv + tv;
+            a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
+            fmac_(Sacc, vI, s);
+            if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
+        } else {
+            a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
+            a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
+            fmac_(Sacc, vI, yv);
+            fmac_(Sacc, vJ, tv);
         }
-        buf ^= 1;
-#if !EIG_MV_PREFETCH
-        if (t < ntiles) issue_tile(buf);
-#endif
-        TSTAMP(0, 4, T0);   // partials stored
-        __syncthreads();
+        ++k;
     }
-    if (wave == 0) {
-        Sacc = wave_sum(Sacc);
-        if (lane == 0) a.S[hb] = Sacc;
-    }
-    TSTAMP(0, 5, T0);       // end
+    Sacc = wave_sum(Sacc);
+    if (lane == 0) a.S[hb] = Sacc;
+    TSTAMP(0, 5, T0);
 }
 
 // y = sum of the hemv partials (stand-alone hemv entry point only)
@@ -642,7 +668,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         int npo = np - 1 - i;
         int gg = (2 * npo * nchunk + 3) / 4;
         a.nblkA = gA * NPW; a.gh = gh; a.nchunk = nchunk;
-        hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(256), 0, st, a, 0, gg);
+        hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(MVT), 0, st, a, 0, gg);
         if (nlaunch) ++*nlaunch;
         if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
         gh_prev = gh; nchunk_prev = nchunk;
@@ -708,7 +734,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
     a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
     a.gh = hemv_grid(c, n);
-    hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(256), 0, st, a, 1, 0);
+    hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(MVT), 0, st, a, 1, 0);
     if (gather) {
         int nt = (n + HT - 1) / HT;
         hipLaunchKernelGGL((hemv_gather_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, n, nt, (const T*)sc.P, sc.ldp, y);
