@@ -269,7 +269,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         double t0 = now_ms();
         double* Qd = nullptr;
         int ldq_d = 0;
-        if (stedc_device(c, st, N, w_d, e_d, w_d, &Qd, &ldq_d) != 0) {
+        if (stedc_device(c, st, N, w_d, e_d, w_d, &Qd, &ldq_d, il, iu) != 0) {
             printf(" eigsolve error: device tridiagonal eigensolver failed!\n");
             return -1;
         }

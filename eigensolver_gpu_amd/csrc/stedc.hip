@@ -403,10 +403,11 @@ __global__ void __launch_bounds__(256) dc_rank_kernel(const MergeDesc* md, const
 // Qnext(:, off+pos) <- Qtmp(:, off+j) (non-deflated) or Qcur(:, dcol[u]) (deflated); Dnext likewise.
 __global__ void __launch_bounds__(256) dc_assemble_kernel(const MergeDesc* md, const double* Qtmp, const double* Qcur, double* Qnext, int ldq,
                                                           const int* pos_nd, const int* pos_df, const int* dcol_all, const double* lam_all,
-                                                          const double* dval_all, double* Dnext) {
+                                                          const double* dval_all, double* Dnext, int tlo, int thi) {
     const MergeDesc m = md[blockIdx.z];
     const int t = blockIdx.y;
     if (t >= m.n) return;
+    const bool skip_vec = t < m.k && (t < tlo || t > thi);   // root merge: vectors outside the wanted range were not computed
     int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= m.n) return;
     const double* src;
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(256) dc_assemble_kernel(const MergeDesc* md, c
         pos = pos_df[m.off + u];
         val = dval_all[m.off + u];
     }
-    Qnext[(size_t)(m.off + row) + (size_t)(m.off + pos) * ldq] = src[m.off + row];
+    if (!skip_vec) Qnext[(size_t)(m.off + row) + (size_t)(m.off + pos) * ldq] = src[m.off + row];
     if (row == 0) Dnext[m.off + pos] = val;
 }
 
@@ -440,7 +441,7 @@ struct Node {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double* e_d, double* w_d, double** Q_out, int* ldq_out) {
+int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double* e_d, double* w_d, double** Q_out, int* ldq_out, int il, int iu) {
     if (N <= 0) return 0;
     // ---- host copies of d, e; scaling; tree; torn diagonal ------------------------------------
     std::vector<double> d(N), e(N > 1 ? N - 1 : 1, 0.0);
@@ -522,6 +523,9 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     int* d_zrow_all = nullptr;
     double* d_zscale_all = nullptr;
     double* h_zD = reinterpret_cast<double*>(c.host_scratch_bytes("dc_zD_h", sizeof(double) * 2 * (size_t)N));
+    int* h_pos = reinterpret_cast<int*>(c.host_scratch_bytes("dc_pos_h", sizeof(int) * (size_t)N));
+    if (iu < 0 || iu > N) iu = N;
+    if (il < 1) il = 1;
     int* d_info = c.d_info + 1;
 
     EIG_HIP(hipMemsetAsync(Qa, 0, NN * sizeof(double), st));
@@ -683,10 +687,28 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             hipLaunchKernelGGL(dc_rotate_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const int*)d_rp,
                                (const int*)d_rq, (const double*)d_rc, (const double*)d_rs, Qcur, ldq);
         }
+        int tlo = 0, thi = N;   // root columns whose vectors are computed (all, except at a partial root merge)
+        const bool root_partial = (level == nlevels) && nm == 1 && h_md[0].n == N && N > 256 && (il > 1 || iu < N) && kmax > 0;
+        if (kmax == 0)
+            hipLaunchKernelGGL(dc_rank_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)d_lam,
+                               (const double*)d_dval, d_posnd, d_posdf);
         if (kmax > 0) {
             const size_t shm = sizeof(double) * 2 * MAXK_LDS;
             hipLaunchKernelGGL(dc_secular_kernel, dim3((kmax + 4 * ROOTS_PER_WAVE - 1) / (4 * ROOTS_PER_WAVE), nm), dim3(256), shm, st,
                                (const MergeDesc*)d_md, (const double*)d_dl, (const double*)d_w, S, ldq, d_lam);
+            // ranks of the new eigenvalues: needed by the assembly, and at the root they tell which vectors are wanted
+            hipLaunchKernelGGL(dc_rank_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)d_lam,
+                               (const double*)d_dval, d_posnd, d_posdf);
+            if (root_partial) {
+                // only eigenvectors il..iu are consumed (zheevd_gpu.F90:110): the roots are ascending, so the wanted ones
+                // are a contiguous range [tlo, thi] of the root merge's columns
+                EIG_HIP(hipMemcpyAsync(h_pos, d_posnd, sizeof(int) * h_md[0].k, hipMemcpyDeviceToHost, st));
+                EIG_HIP(hipStreamSynchronize(st));
+                const int kroot = h_md[0].k;
+                tlo = kroot; thi = -1;
+                for (int q = 0; q < kroot; ++q)
+                    if (h_pos[q] >= il - 1 && h_pos[q] <= iu - 1) { if (q < tlo) tlo = q; thi = q; }
+            }
             hipLaunchKernelGGL(dc_zhat_kernel, dim3((kmax + 3) / 4, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)d_dl,
                                (const double*)d_w, (const double*)S, ldq, d_zhat);
             hipLaunchKernelGGL(dc_vectors_kernel, dim3(kmax, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)d_zhat,
@@ -704,26 +726,27 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             for (const MergeDesc& m : h_md) {
                 if (m.k == 0) continue;
                 const int k12 = m.k1 + m.k2, k23 = m.k2 + m.k3;
-                double* Ct = S + (size_t)m.off + (size_t)m.off * ldq;
+                // columns of the result that are needed: all of them, or [tlo, thi] at a partial root merge
+                const int c0 = root_partial ? tlo : 0, nc = root_partial ? thi - tlo + 1 : m.k;
+                if (nc <= 0) continue;
+                double* Ct = S + (size_t)m.off + (size_t)(m.off + c0) * ldq;
                 if (k12 > 0)
-                    gemm<double>(c, st, m.n1, m.k, k12, 1.0, opA('N', (const double*)(Qg + (size_t)m.off + (size_t)m.off * ldq), ldq),
-                                 opB('N', (const double*)(S2 + (size_t)m.off + (size_t)m.off * ldq), ldq), 0.0, Ct, ldq);
+                    gemm<double>(c, st, m.n1, nc, k12, 1.0, opA('N', (const double*)(Qg + (size_t)m.off + (size_t)m.off * ldq), ldq),
+                                 opB('N', (const double*)(S2 + (size_t)m.off + (size_t)(m.off + c0) * ldq), ldq), 0.0, Ct, ldq);
                 else
-                    EIG_HIP(hipMemset2DAsync(Ct, sizeof(double) * ldq, 0, sizeof(double) * m.n1, m.k, st));
+                    EIG_HIP(hipMemset2DAsync(Ct, sizeof(double) * ldq, 0, sizeof(double) * m.n1, nc, st));
                 double* Cb = Ct + m.n1;
                 if (k23 > 0)
-                    gemm<double>(c, st, m.n2, m.k, k23, 1.0,
+                    gemm<double>(c, st, m.n2, nc, k23, 1.0,
                                  opA('N', (const double*)(Qg + (size_t)(m.off + m.n1) + (size_t)(m.off + m.k1) * ldq), ldq),
-                                 opB('N', (const double*)(S2 + (size_t)(m.off + m.k1) + (size_t)m.off * ldq), ldq), 0.0, Cb, ldq);
+                                 opB('N', (const double*)(S2 + (size_t)(m.off + m.k1) + (size_t)(m.off + c0) * ldq), ldq), 0.0, Cb, ldq);
                 else
-                    EIG_HIP(hipMemset2DAsync(Cb, sizeof(double) * ldq, 0, sizeof(double) * m.n2, m.k, st));
+                    EIG_HIP(hipMemset2DAsync(Cb, sizeof(double) * ldq, 0, sizeof(double) * m.n2, nc, st));
             }
         }
-        hipLaunchKernelGGL(dc_rank_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)d_lam,
-                           (const double*)d_dval, d_posnd, d_posdf);
         hipLaunchKernelGGL(dc_assemble_kernel, dim3((nmax + 255) / 256, nmax, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const double*)S,
                            (const double*)Qcur, Qnext, ldq, (const int*)d_posnd, (const int*)d_posdf, (const int*)d_dcol,
-                           (const double*)d_lam, (const double*)d_dval, Dnext);
+                           (const double*)d_lam, (const double*)d_dval, Dnext, tlo, thi);
         EIG_HIP(hipGetLastError());
         // blocks not merged at this level (subtrees that are one level shallower) carry over unchanged
         for (int id = 0; id < (int)nodes.size(); ++id) {
