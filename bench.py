@@ -4,21 +4,26 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N>1: under torchrun, one rank per GPU)
 prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json metric / configs[2], "C3"):  zhegvdx, fp64 complex, N=4096,
-eigenpairs 1..1024, reference input recipe (A = T T^H, B = T' T'^H, test_zhegvdx.F90:28-66),
-lda=ldb=ldz=N, workspaces at the reference's minimum sizes.  A "step" is one full solve through the
-C ABI (potrf -> gst -> trd -> host dstedc -> back-transform -> trsm -> D2H of Z), inputs already
-resident in HBM when the timed region starts (W+K pristine (A,B) pairs are staged beforehand: the
-solver destroys its inputs).  N GPUs = N independent problems per step (QE k-point style, weak
-scaling, no data-path collective); value = problems/s over all ranks.
+Default workload (BASELINE.json metric / configs[2], "C3"):  zhegvdx, fp64 complex, N=4096, eigenpairs 1..1024,
+reference input recipe (A = T T^H, B = T' T'^H, test_zhegvdx.F90:28-66), lda=ldb=ldz=N, workspaces at the reference's
+minimum sizes.  A "step" is a batch of `--batch` independent, DISTINCT problems per GPU (QE k-point style), each one full
+solve through the C ABI (potrf -> gst -> trd -> tridiagonal solver -> back-transform -> trsm -> D2H of Z), `--inflight`
+of them in flight per GPU on persistent host threads (one library context each).  Inputs are already resident in HBM when
+the timed region starts ((W+K) x batch pristine (A,B) pairs are staged beforehand: the solver destroys its inputs).
+N GPUs = N x batch problems per step (weak scaling, no data-path collective); value = problems/s over all ranks.
+
+--workload c5 (BASELINE.json configs[4]): a step = ONE pass over a fixed batch of 64 distinct zhegvdx N=2048 m=512
+problems sharded p -> rank (p mod G) (eigensolver_gpu_amd/batch.py), strong scaling; the eigenvalues are gathered over
+RCCL after the timed region.  The default line carries the same measurement as the `c5` object.
 
 Extra objects on the same line:
-  roofline      dominant kernel = panel_mv_kernel (hemv + stacked gemv, HBM-bound).  achieved =
-                algorithmic bytes (sum_n s*n(n+1)/2 over the launches of one tridiagonalization,
-                SURVEY.md 8(d)) / HIP-event time of exactly that launch sequence, measured live.
+  roofline      dominant kernel = panel_mv_kernel (hemv + stacked gemv, HBM-bound).  achieved = algorithmic bytes
+                (sum_n s*n(n+1)/2 over the launches of one tridiagonalization) / HIP-event time of
+                exactly that launch sequence on the library's stream, measured live.
   roofline_mfma her2k (trd trailing update) and gemm on the fp64 MFMA engine vs 78.6 TFLOP/s.
-  cpu_baseline  LAPACK zhegvx (scipy/OpenBLAS, the routine the reference mirrors and its test
-                driver's CPU case) on the host cores, same recipe, bounded sample.
+  host_tridiag  one isolated solve with the tridiagonal step on the host LAPACK dstedc (the reference's behaviour).
+  cpu_baseline  LAPACK zhegvx (the routine the reference mirrors) and zhegvd (what its test driver times,
+                test_zhegvdx.F90:172-184) on the host cores, on the SAME (A,B) as the first GPU problem.
 """
 import argparse
 import json
@@ -31,6 +36,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TF = 78.6    # MI355X datasheet fp64 matrix
+EPS = 2.220446049250313e-16
+C5_PROBLEMS = 64
 
 
 def gen_pair(n, cplx, seed, device, shift_b=0.0):
@@ -50,9 +57,14 @@ def gen_pair(n, cplx, seed, device, shift_b=0.0):
         M = 0.5 * (M + M.conj().T)
         if k == 1 and shift_b:
             M = M + shift_b * torch.eye(n, device=device, dtype=M.dtype)
-        out.append(M.contiguous())   # Hermitian: row-major == column-major of the conjugate; take conj below
+        out.append(M.contiguous())
     # column-major storage of M is the row-major storage of M^T = conj(M) for Hermitian M
     return torch.conj_physical(out[0]).contiguous(), torch.conj_physical(out[1]).contiguous()
+
+
+def problem_seed(cfg_index, p, step):
+    """seed 1000+config_index, batch problem p adds 17*p; every step gets its own problems."""
+    return 1000 + cfg_index + 17 * p + 100003 * step
 
 
 def work_model(n, m, cplx):
@@ -62,30 +74,48 @@ def work_model(n, m, cplx):
     return total, blas3
 
 
+def check_solution(torch, A0, B0, Zt, wv, m):
+    """residual, max backward error, B-orthonormality of a device solution against pristine inputs (checker only)."""
+    Zc = Zt[:m, :].T                       # N x m view
+    Ah, Bh = A0.T, B0.T
+    BZ = Bh @ Zc
+    R = Ah @ Zc - BZ * wv.to(Zc.dtype)[None, :]
+    nA, nB = torch.linalg.norm(Ah), torch.linalg.norm(Bh)
+    resid = float(torch.linalg.norm(R) / nA)
+    # standard backward error of a generalized eigenpair ||A z - w B z|| / ((||A|| + |w| ||B||) ||z||): with the
+    # reference recipe cond(B) reaches 1e10, so at full spectrum the unscaled residual is dominated by |w| ||B||
+    berr = float((torch.linalg.norm(R, dim=0) / ((nA + wv.abs() * nB) * torch.linalg.norm(Zc, dim=0))).max())
+    G = Zc.conj().T @ BZ
+    bortho = float(torch.linalg.norm(G - torch.eye(m, device=G.device, dtype=G.dtype)))
+    return resid, berr, bortho
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=4096)
-    ap.add_argument("--m", type=int, default=1024)
+    ap.add_argument("--workload", choices=["c3", "c5"], default="c3")
+    ap.add_argument("--n", type=int, default=0, help="override the order (default: 4096 for c3, 2048 for c5)")
+    ap.add_argument("--m", type=int, default=0, help="override the number of eigenpairs (default: n/4)")
     ap.add_argument("--real", action="store_true", help="dsygvdx instead of zhegvdx")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=0, help="order of the CPU baseline sample (default: min(n, 4096): "
-                    "the full C3 problem, one timed LAPACK call, about 20 s on the GPU box's host)")
-    ap.add_argument("--batch", type=int, default=2,
-                    help="independent problems per GPU per step (QE k-point style batch); solved by min(batch, --inflight) "
-                         "host threads, each with its own context/stream")
-    ap.add_argument("--inflight", type=int, default=2, help="problems in flight per GPU (host threads / contexts)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the `c5` object of the default line")
+    ap.add_argument("--no-host-tridiag", action="store_true")
+    ap.add_argument("--batch", type=int, default=2, help="(c3) independent problems per GPU per step")
+    ap.add_argument("--inflight", type=int, default=2, help="problems in flight per GPU (persistent host threads / contexts)")
+    ap.add_argument("--isolated-reps", type=int, default=3, help="isolated single solves timed before the batch (median/min reported)")
     ap.add_argument("--tridiag", choices=["device", "host"], default="device",
                     help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
+    ap.add_argument("--log-steps", action="store_true", help="add per-step wall ms to the line")
     args = ap.parse_args()
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
     from eigensolver_gpu_amd import api
+    from eigensolver_gpu_amd.batch import InflightPool, gather_eigenvalues, run_sharded_batch, shard_problems
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -97,23 +127,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
     cplx = not args.real
-    n, m = args.n, args.m
+    c5 = args.workload == "c5"
+    n = args.n or (2048 if c5 else 4096)
+    m = args.m or n // 4
     K, W = args.steps, args.warmup
     cores = os.cpu_count() or 1
-    # each rank's host dstedc gets an equal share of the host cores
     api.lib()
-    api.set_host_threads(max(1, min(64, cores // max(world, 1))))
-    api.set_option("tridiag", 1 if args.tridiag == "device" else 0)
-
-    # ---- stage (W+K)*P pristine input pairs in HBM ---------------------------------------------
-    import threading
-    P = max(1, args.batch)
-    nthr = max(1, min(P, args.inflight))
-    A0, B0 = gen_pair(n, cplx, 1000 + rank, dev)
-    pairs = [(A0.clone(), B0.clone()) for _ in range((W + K) * P)]
-    wss = [api.Workspace(n, cplx) for _ in range(nthr)]
-    ws = wss[0]
-    torch.cuda.synchronize()
+    api.set_host_threads(max(1, min(64, cores // max(world, 1))))   # each rank's host LAPACK gets its share of the cores
+    tri = 1 if args.tridiag == "device" else 0
+    api.set_option("tridiag", tri)
+    nthr = max(1, args.inflight)
 
     def barrier():
         torch.cuda.synchronize()
@@ -121,138 +144,245 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    tri = 1 if args.tridiag == "device" else 0
+    # ---- persistent in-flight workers: one library context (streams, scratch) per worker thread -----------------
+    wss = {}
+
+    def worker_init(t):
+        torch.cuda.set_device(local)
+        api.set_option("tridiag", tri)
+
+    pool = InflightPool(nthr, init=worker_init)
+
+    def workspace(t, nn):
+        key = (t, nn)
+        if key not in wss:
+            wss[key] = api.Workspace(nn, cplx)
+        return wss[key]
+
+    # ---- the batch of one step: total problems and this rank's share ----------------------------------------------
+    cfg_index = 4 if c5 else 2
+    n_total = C5_PROBLEMS if c5 else max(1, args.batch) * world
+    mine = shard_problems(n_total, rank, world)
+    staged = {}
+    for s in range(W + K):
+        for p in mine:
+            staged[(s, p)] = gen_pair(n, cplx, problem_seed(cfg_index, p, s), dev)
+    for t in range(nthr):
+        workspace(t, n)
+    torch.cuda.synchronize()
     phases = []
-    errors = []
+    last = {}
 
-    def worker(t, items):
-        # one context per (host thread, device): the options are per context
+    def make_solver(step):
+        def solve(p, t):
+            A, B = staged[(step, p)]
+            ws = workspace(t, n)
+            info, _ = api.hegvdx(A, B, 1, m, ws)
+            if info != 0:
+                raise RuntimeError("hegvdx info=%d (problem %d, step %d)" % (info, p, step))
+            if t == 0:
+                phases.append(api.phase_times())
+                last["p"], last["step"] = p, step
+            return ws.w[:m].clone()
+        return solve
+
+    # ---- isolated single-solve latency (untimed region, part of the warm-up): 1 warm-up + >= 3 timed -------------
+    A0, B0 = gen_pair(n, cplx, problem_seed(cfg_index, mine[0] if mine else 0, 0), dev)
+    ws0 = api.Workspace(n, cplx)
+    iso, iso_ph = [], []
+    for r in range(1 + max(1, args.isolated_reps)):
+        Ai, Bi = A0.clone(), B0.clone()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        info, _ = api.hegvdx(Ai, Bi, 1, m, ws0)
+        wall = (time.perf_counter() - t1) * 1e3
+        assert info == 0
+        if r > 0:
+            iso.append(wall)
+            iso_ph.append(api.phase_times())
+    order = sorted(range(len(iso)), key=lambda i: iso[i])
+    single_phases = iso_ph[order[len(order) // 2]]
+    host_tri = None
+    if tri == 1 and not args.no_host_tridiag and rank == 0:
+        api.set_option("tridiag", 0)
         try:
-            torch.cuda.set_device(local)
-            api.set_option("tridiag", tri)
-            for s_ in items:
-                info, _ = api.hegvdx(pairs[s_][0], pairs[s_][1], 1, m, wss[t])
-                if info != 0:
-                    errors.append(info)
-                if t == 0:
-                    phases.append(api.phase_times())
-        except Exception as ex:  # noqa
-            errors.append(repr(ex))
+            Ai, Bi = A0.clone(), B0.clone()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            info, _ = api.hegvdx(Ai, Bi, 1, m, ws0)
+            host_tri = {"ms_per_solve": (time.perf_counter() - t1) * 1e3, "phase_ms": api.phase_times(), "info": info,
+                        "note": "same isolated solve with the tridiagonal step on the host LAPACK dstedc, as in the "
+                                "reference (zheevd_gpu.F90:101); %d host threads" % max(1, min(64, cores // max(world, 1)))}
+        finally:
+            api.set_option("tridiag", 1)
+    del Ai, Bi
 
-    def run_step(step):
-        items = list(range(step * P, (step + 1) * P))
-        if nthr == 1:
-            worker(0, items)
-            return
-        ths = [threading.Thread(target=worker, args=(t, items[t::nthr])) for t in range(nthr)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-
-    # isolated single-solve latency (untimed region, part of the warm-up)
-    t1 = time.perf_counter()
-    info, _ = api.hegvdx(A0.clone(), B0.clone(), 1, m, ws)
-    torch.cuda.synchronize()
-    assert info == 0
-    info, _ = api.hegvdx(A0.clone(), B0.clone(), 1, m, ws)
-    torch.cuda.synchronize()
-    single_phases = api.phase_times()
-    single_ms = single_phases["total"]
+    # ---- warm-up steps, then EXACTLY K timed steps between barriers ------------------------------------------------
     for s in range(W):
-        run_step(s)
-    assert not errors, errors
+        run_sharded_batch(n_total, rank, world, make_solver(s), pool)
     phases.clear()
     barrier()
+    step_ms = []
     t0 = time.perf_counter()
+    results = None
     for s in range(W, W + K):
-        run_step(s)
+        ts = time.perf_counter()
+        results = run_sharded_batch(n_total, rank, world, make_solver(s), pool)
+        if args.log_steps:
+            torch.cuda.synchronize()
+            step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
-    elapsed = time.perf_counter() - t0
-    assert not errors, errors
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
+    rank_ms = [elapsed_local * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=dev)
+        allt = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) * 1e3 for x in allt]
+        elapsed = max(rank_ms) / 1e3
 
-    # ---- validity: residual of the last solve against pristine inputs (outside the timed region) ----
-    Z = ws.Z[:m, :]                       # (m, N) row-major == N x m column-major
-    Zc = Z.T                              # N x m view
-    wv = ws.w[:m]
-    Ah, Bh = A0.T, B0.T                   # back to math orientation
-    R = Ah @ Zc - (Bh @ Zc) * wv.to(Zc.dtype)[None, :]
-    nA, nB = torch.linalg.norm(Ah), torch.linalg.norm(Bh)
-    resid = float(torch.linalg.norm(R) / nA)
-    # standard backward error of a generalized eigenpair: ||A z - w B z|| / ((||A|| + |w| ||B||) ||z||).  With the
-    # reference recipe cond(B) reaches 1e10 and the top of the spectrum 1e7, so at full spectrum (configs[3]) the
-    # unscaled `residual` is dominated by |w| ||B||; LAPACK behaves the same.
-    berr = float((torch.linalg.norm(R, dim=0) / ((nA + wv.abs() * nB) * torch.linalg.norm(Zc, dim=0))).max())
-    G = Zc.conj().T @ (Bh @ Zc)
-    bortho = float(torch.linalg.norm(G - torch.eye(m, device=dev, dtype=G.dtype)))
-    del R, G
-
+    # ---- validity: residual of worker 0's last solve against its pristine inputs (outside the timed region) -------
+    resid = berr = bortho = None
+    if "p" in last:
+        Ap, Bp = gen_pair(n, cplx, problem_seed(cfg_index, last["p"], last["step"]), dev)
+        wsl = workspace(0, n)
+        resid, berr, bortho = check_solution(torch, Ap, Bp, wsl.Z, wsl.w[:m], m)
+        del Ap, Bp
     # optional result gather over RCCL/xGMI (outside the timed region; north_star: gather only)
-    if world > 1:
-        allw = [torch.empty_like(wv) for _ in range(world)]
-        dist.all_gather(allw, wv.contiguous())
+    gathered = gather_eigenvalues(results or {}, n_total, m)
+    staged.clear()
+    torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
         total_fl, blas3_fl = work_model(n, m, cplx)
         ms_step = elapsed * 1e3 / K
-        ph = dict(single_phases)   # per-phase breakdown of the isolated solve
+        ph = dict(single_phases)
         gpu_ms = ph["potrf"] + ph["gst"] + ph["trd"] + ph["backtransform"] + ph["trsm"]
+        name = "zhegvdx" if cplx else "dsygvdx"
+        if c5:
+            metric = "%s_n%d_m%d_batch%d_problems_per_s" % (name, n, m, C5_PROBLEMS)
+            workload = ("%s N=%d eigenpairs 1..%d; a step = one pass over a fixed batch of %d distinct problems sharded "
+                        "p -> GPU (p mod %d), %d in flight per GPU" % (name, n, m, C5_PROBLEMS, world, nthr))
+        else:
+            metric = "zhegvdx_n4096_m1024_problems_per_s" if (cplx and n == 4096 and m == 1024) else \
+                     "%s_n%d_m%d_problems_per_s" % (name, n, m)
+            workload = ("%s N=%d eigenpairs 1..%d; a step = a batch of %d independent, distinct problems per GPU "
+                        "(QE k-point style), %d in flight per GPU (one persistent host thread + context + stream each)" %
+                        (name, n, m, len(mine), nthr))
         out = {
-            "metric": "zhegvdx_n4096_m1024_problems_per_s" if (cplx and n == 4096 and m == 1024) else
-                      "%s_n%d_m%d_problems_per_s" % ("zhegvdx" if cplx else "dsygvdx", n, m),
-            "value": world * K * P / elapsed,
+            "metric": metric,
+            "value": n_total * K / elapsed,
             "unit": "problems/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if c5 else "weak",
             "vs_baseline": None,
             "dtype": "c128" if cplx else "f64",
-            "data": "synthetic (reference recipe A=T*T^H, B=T'*T'^H, uniform[0,1) entries, seeded)",
-            "config": {"workload": "%s N=%d eigenpairs 1..%d; a step = a batch of %d independent problems per GPU "
-                                   "(QE k-point style), %d in flight per GPU (one host thread + context + stream each)" %
-                       ("zhegvdx" if cplx else "dsygvdx", n, m, P, nthr), "lda": n, "il": 1, "iu": m,
-                       "problems_per_gpu_per_step": P, "inflight_per_gpu": nthr,
+            "data": "synthetic (reference recipe A=T*T^H, B=T'*T'^H, uniform[0,1) entries, seeded; every problem distinct)",
+            "config": {"workload": workload, "lda": n, "il": 1, "iu": m, "problems_per_step_total": n_total,
+                       "problems_per_gpu_per_step": len(mine), "inflight_per_gpu": nthr,
                        "parallelism": "batch-over-gpus x%d" % world},
-            "ms_per_solve": single_ms,
-            "ms_per_solve_note": "wall time of ONE isolated solve (nothing else in flight), measured before the timed region",
-            "ms_per_problem_in_batch": ms_step / P,
-            "tflops_total_model": total_fl * P / (ms_step * 1e-3) * 1e-12,
+            "ms_per_solve": sorted(iso)[len(iso) // 2],
+            "ms_per_solve_min": min(iso),
+            "ms_per_solve_samples": iso,
+            "ms_per_solve_note": "host wall time around the C-ABI call of ONE isolated solve (nothing else in flight), "
+                                 "1 warm-up + %d timed, median reported; measured before the timed region" % len(iso),
+            "ms_per_problem_in_batch": ms_step / max(1, len(mine)),
+            "rank_elapsed_ms_min_max": [min(rank_ms), max(rank_ms)],
+            "tflops_total_model": total_fl * n_total / world / (ms_step * 1e-3) * 1e-12,
             "tflops_gpu_phases": total_fl / (gpu_ms * 1e-3) * 1e-12 if gpu_ms > 0 else None,
             "phase_ms_single_solve": ph,
-            "residual": resid, "residual_bound_N_eps": n * 2.220446049250313e-16, "backward_error_max": berr,
+            "residual": resid, "residual_bound_N_eps": n * EPS, "backward_error_max": berr,
             "b_orthonormality": bortho,
+            "eigenvalues_gathered": list(gathered.shape) if gathered is not None else None,
             "host_cores": cores,
-            "tridiagonal_solver": "device divide&conquer (stedc.hip)" if args.tridiag == "device" else "host LAPACK dstedc (reference behaviour)",
+            "tridiagonal_solver": "device divide&conquer (stedc.hip)" if tri else "host LAPACK dstedc (reference behaviour)",
         }
+        if host_tri:
+            out["host_tridiag"] = host_tri
+        if args.log_steps:
+            out["step_ms"] = step_ms
 
-    # ---- roofline legs (rank 0, N=1 semantics: run on this rank's GPU after the timed region) --------
+    # ---- C5 object of the default line: 64 distinct zhegvdx N=2048 m=512 problems sharded over the ranks ----------
+    if not c5 and not args.no_c5 and cplx:
+        n5, m5 = 2048, 512
+        mine5 = shard_problems(C5_PROBLEMS, rank, world)
+        st5 = {p: gen_pair(n5, True, problem_seed(4, p, 0), dev) for p in mine5}
+        warm = {t: gen_pair(n5, True, problem_seed(4, 1000 + t, 0), dev) for t in range(nthr)}
+
+        def solve5(p, t):
+            A, B = st5[p]
+            ws = workspace(t, n5)
+            info, _ = api.hegvdx(A, B, 1, m5, ws)
+            if info != 0:
+                raise RuntimeError("c5 hegvdx info=%d (problem %d)" % (info, p))
+            return ws.w[:m5].clone()
+
+        def warm5(t_, t):
+            A, B = warm[t]
+            api.hegvdx(A, B, 1, m5, workspace(t, n5))
+            return 0
+
+        pool.map(warm5, list(range(nthr)))     # sizes every context's scratch for N=2048 outside the timed pass
+        barrier()
+        t5 = time.perf_counter()
+        res5 = run_sharded_batch(C5_PROBLEMS, rank, world, solve5, pool)
+        barrier()
+        el5 = time.perf_counter() - t5
+        r5 = [el5 * 1e3]
+        if world > 1:
+            t = torch.tensor([el5], dtype=torch.float64, device=dev)
+            allt = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            r5 = [float(x.item()) * 1e3 for x in allt]
+        g5 = gather_eigenvalues(res5, C5_PROBLEMS, m5)     # RCCL all_gather (the only collective; after the timing)
+        # validity of one problem of this rank's share
+        p_chk = mine5[-1]
+        Ap, Bp = gen_pair(n5, True, problem_seed(4, p_chk, 0), dev)
+        A2, B2 = Ap.clone(), Bp.clone()
+        wsc = workspace(0, n5)
+        api.hegvdx(A2, B2, 1, m5, wsc)
+        rs5, be5, bo5 = check_solution(torch, Ap, Bp, wsc.Z, wsc.w[:m5], m5)
+        same = bool(torch.equal(wsc.w[:m5], res5[p_chk]))
+        if rank == 0:
+            out["c5"] = {"workload": "64 distinct zhegvdx N=2048 eigenpairs 1..512, p -> GPU (p mod %d), %d in flight per GPU, "
+                                     "ONE pass" % (world, nthr),
+                         "value": C5_PROBLEMS / (max(r5) * 1e-3), "unit": "problems/s", "scaling": "strong",
+                         "elapsed_ms": max(r5), "rank_elapsed_ms_min_max": [min(r5), max(r5)],
+                         "problems_per_gpu": len(mine5), "gathered_eigenvalues_shape": list(g5.shape),
+                         "gathered_checksum": float(g5.sum()), "residual_checked_problem": rs5,
+                         "residual_bound_N_eps": n5 * EPS, "b_orthonormality_checked_problem": bo5,
+                         "rerun_bit_identical": same}
+        del st5, warm, Ap, Bp, A2, B2
+        torch.cuda.empty_cache()
+
+    # ---- roofline legs (rank 0, on this rank's GPU after the timed region) -----------------------------------------
     if rank == 0 and not args.no_roofline:
         s_el = 16 if cplx else 8
-        Asw = pairs[-1][0]
+        Asw = A0.clone()
         r = api.hetrd_mv_sweep(Asw, 0, reps=2)
         per_launch_ms = r["ms_total"] / r["launches"]
         per_launch_bytes = r["algo_bytes"] / r["launches"]
         ach = r["algo_bytes"] / (r["ms_total"] * 1e-3) * 1e-9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "hemv_traffic.json")
-        if os.path.exists(tp):
-            try:
-                # PMC FETCH_SIZE/WRITE_SIZE were collected on single n=4096 launches (a PMC pass over a whole
-                # solve takes >30 min); the measured traffic/algorithmic ratio is applied to this run's bytes.
-                traffic = json.load(open(tp)).get("traffic_over_algorithmic") * per_launch_bytes
-            except Exception:
-                traffic = None
+        tfp = None
+        for nm in ("r02_hemv_traffic.json", "hemv_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", nm)
+            if os.path.exists(tp):
+                try:
+                    tfp = {"file": "profiles/" + nm, "traffic_over_algorithmic": json.load(open(tp)).get("traffic_over_algorithmic"),
+                           "note": "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE pass of an earlier run, NOT measured in this run"}
+                except Exception:
+                    tfp = None
+                break
         out["roofline"] = {"bound": "hbm", "kernel": "panel_mv_kernel (hemv+stacked gemv), %d launches of one hetrd N=%d" % (r["launches"], n),
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "algo_bytes_per_launch": per_launch_bytes, "avg_launch_us": per_launch_ms * 1e3}
+                           "traffic": None, "traffic_from_profile": tfp,
+                           "algo_bytes_per_launch": per_launch_bytes, "avg_launch_us": per_launch_ms * 1e3}
         # largest single hemv (n = N-1): what the kernel sustains when the operand is at full size
         x = torch.ones(n, dtype=Asw.dtype, device=dev)
         ms1 = api.hemv_bench(A0, x, reps=20)
@@ -271,37 +401,51 @@ def main():
         msg = api.gemm_bench("N", "N", n, n, n, A0, n, Bm, n, Cm, n, reps=3)
         fl_gemm = cmul * 2.0 * n ** 3
         blas3_ms = ph["potrf"] + ph["gst"] + ph["backtransform"] + ph["trsm"]
+        fl_ph = {"potrf": cmul * n ** 3 / 3.0, "gst": cmul * n ** 3, "backtransform": cmul * 2.0 * n * n * m, "trsm": cmul * n * n * m}
         out["roofline_mfma"] = {
             "bound": "mfma", "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
             "her2k_k64": {"achieved": fl_her2k / (msk * 1e-3) * 1e-12, "frac": fl_her2k / (msk * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msk},
             "gemm_nn": {"achieved": fl_gemm / (msg * 1e-3) * 1e-12, "frac": fl_gemm / (msg * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msg},
             "blas3_phases_in_solve": {"achieved": (cmul * ((4.0 / 3.0) * n ** 3 + 3.0 * n * n * m)) / (blas3_ms * 1e-3) * 1e-12 if blas3_ms > 0 else None,
-                                      "note": "potrf+gst+back-transform+trsm model flops / their HIP-event time"},
+                                      "frac": (cmul * ((4.0 / 3.0) * n ** 3 + 3.0 * n * n * m)) / (blas3_ms * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF if blas3_ms > 0 else None,
+                                      "per_phase_tflops": {k: fl_ph[k] / (ph[k] * 1e-3) * 1e-12 for k in fl_ph if ph[k] > 0},
+                                      "note": "potrf+gst+back-transform+trsm model flops / their HIP-event time in the isolated solve"},
         }
-        del V, Wm, C, Bm, Cm
+        del V, Wm, C, Bm, Cm, Asw
 
-    # ---- CPU baseline (rank 0 only, bounded sample) --------------------------------------------------
+    # ---- CPU baseline (rank 0 only, N=1 only): LAPACK on the host cores, SAME (A,B) as the first GPU problem --------
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         import scipy.linalg as sl
-        cn = args.cpu_n or min(n, 4096)
-        cm = max(1, cn * m // n)
-        Ac, Bc = gen_pair(cn, cplx, 4242, dev)
-        Ah_np = Ac.T.cpu().numpy()
-        Bh_np = Bc.T.cpu().numpy()
+        Ah_np = A0.T.cpu().numpy()
+        Bh_np = B0.T.cpu().numpy()
+        # warm-up (thread pool, pages) on a leading block -- the reference's driver runs the CPU case once before timing
+        # it (test_zhegvdx.F90:172); a full-size warm-up would double the bench's run time
+        sl.eigh(Ah_np[:512, :512], Bh_np[:512, :512] + 512 * np.eye(512), subset_by_index=[0, 127], driver="gvx")
         t1 = time.perf_counter()
-        wc, Zc_np = sl.eigh(Ah_np, Bh_np, subset_by_index=[0, cm - 1], driver="gvx")
+        wc, Zc_np = sl.eigh(Ah_np, Bh_np, subset_by_index=[0, m - 1], driver="gvx")
         tc = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        wd = sl.eigh(Ah_np, Bh_np, driver="gvd", eigvals_only=False)[0]
+        td = time.perf_counter() - t1
         try:
             from threadpoolctl import threadpool_info
             nth = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
         except Exception:
             nth = cores
+        pfx = "z" if cplx else "d"
+        wg = ws0.w[:m].cpu().numpy()
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "problems/s", "cores": nth, "kind": "port",
-                               "sample": "LAPACK %s (scipy %s / OpenBLAS) N=%d eigenpairs 1..%d, same recipe, one timed call; "
-                                         "this is the routine the reference mirrors (README.md:19-20) and what its test driver "
-                                         "times on the CPU" % ("zhegvx" if cplx else "dsygvx", __import__("scipy").__version__, cn, cm),
-                               "ms": tc * 1e3}
+                               "sample": "LAPACK %s (scipy %s / OpenBLAS) on the SAME (A,B) as the isolated GPU solve: N=%d eigenpairs "
+                                         "1..%d, after a small warm-up call, one timed call; this is the routine the reference mirrors "
+                                         "(README.md:19-20)" % (pfx + ("hegvx" if cplx else "sygvx"), __import__("scipy").__version__, n, m),
+                               "ms": tc * 1e3,
+                               "gvd": {"ms": td * 1e3, "value": 1.0 / td,
+                                       "sample": "LAPACK %s (all N eigenpairs), what the reference's test driver times on the CPU "
+                                                 "(test_zhegvdx.F90:172-184), same (A,B), one timed call" % (pfx + ("hegvd" if cplx else "sygvd"))},
+                               "eigenvalue_l2_gpu_vs_gvx": float(np.linalg.norm(wg - wc) / np.linalg.norm(wc)),
+                               "eigenvalue_l2_gvd_vs_gvx": float(np.linalg.norm(wd[:m] - wc) / np.linalg.norm(wc))}
 
+    pool.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -37,7 +37,7 @@ EXPORTS = [
     "eigsolve_dsymv_bench", "eigsolve_zgemm", "eigsolve_dgemm", "eigsolve_zgemm_bench", "eigsolve_dgemm_bench",
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
     "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
-    "eigsolve_dstedc_device",
+    "eigsolve_dstedc_device", "eigsolve_zlarft", "eigsolve_dlarft", "eigsolve_zunmtr", "eigsolve_dormtr",
 ]
 
 
@@ -363,6 +363,33 @@ def hetrd_mv_sweep(A_d, nb=0, reps=1):
                               ctypes.byref(nl), ctypes.byref(by))
     assert rc == 0
     return {"ms_total": ms.value, "launches": nl.value, "algo_bytes": by.value}
+
+
+def larft(A_d, tau_d, nb=128):
+    """All T factors (zlarft_gpu, zheevd_gpu.F90:136-176) of a tridiagonalized A_d.  Returns a numpy array
+    (nblk, ldt, ldt) of lower-triangular blocks (math orientation)."""
+    import torch
+    _sync()
+    N = A_d.shape[0]
+    k = N - 1
+    nbe = min(nb if nb == 64 else 128, N)
+    ldt = 128 if nbe > 64 else 64
+    nblk = max(1, (k + nbe - 1) // nbe)
+    T = torch.zeros((nblk, ldt, ldt), dtype=A_d.dtype, device="cuda")
+    name = "eigsolve_zlarft" if _pre(A_d) == "z" else "eigsolve_dlarft"
+    rc = getattr(lib(), name)(c_int(N), _p(A_d), c_int(A_d.shape[1]), _p(tau_d), c_int(nb), _p(T), c_int(ldt))
+    assert rc == 0
+    return T.cpu().numpy().transpose(0, 2, 1)
+
+
+def unmtr(A_d, tau_d, Z_d, m, nb=128):
+    """Z(:, :m) <- Q Z with Q from the reflectors in upper(A_d) (the zlarft_gpu / zlarfb_gpu loop, zheevd_gpu.F90:113-131)."""
+    _sync()
+    N = A_d.shape[0]
+    name = "eigsolve_zunmtr" if _pre(A_d) == "z" else "eigsolve_dormtr"
+    rc = getattr(lib(), name)(c_int(N), c_int(m), _p(A_d), c_int(A_d.shape[1]), _p(tau_d), _p(Z_d), c_int(Z_d.shape[1]),
+                              c_int(nb))
+    assert rc == 0
 
 
 def stedc_device(d, e):

@@ -4,12 +4,92 @@ The reference has no multi-GPU code (single GPU, process-global state, eigsolve_
 a single solve is a chain of dependent Householder steps and does not shard.  A batch shards
 embarrassingly: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI), static
 block-cyclic assignment, NO collective on the data path.  RCCL is used only for the optional
-gather of results and for the benchmark's timing reduction."""
+gather of results and for the benchmark's timing reduction.
+
+Inside one process several problems are kept in flight on the GPU by a small pool of PERSISTENT host
+threads: the library keeps one context (streams, events, cached scratch) per (host thread, device), so the
+threads must live as long as the batch does -- a context dies with its thread."""
+import queue
+import threading
 
 
 def shard_problems(n_problems, rank, world):
     """Static block-cyclic partition p -> rank (p mod world)."""
     return [p for p in range(n_problems) if p % world == rank]
+
+
+class InflightPool:
+    """`nthr` persistent worker threads.  `init(t)` runs once in worker t (device selection, solver options: the
+    library's options are per context, i.e. per thread); `map(fn, items)` hands items[t::nthr] to worker t, which
+    calls fn(item, t) for each, and returns the results in item order.  The first worker exception is re-raised."""
+
+    def __init__(self, nthr, init=None):
+        self.nthr = max(1, int(nthr))
+        self._in = [queue.Queue() for _ in range(self.nthr)]
+        self._out = queue.Queue()
+        self._threads = [threading.Thread(target=self._run, args=(t, init), daemon=True) for t in range(self.nthr)]
+        for th in self._threads:
+            th.start()
+
+    def _run(self, t, init):
+        err = None
+        try:
+            if init is not None:
+                init(t)
+        except BaseException as ex:  # noqa: BLE001 -- reported to the caller of map()
+            err = ex
+        while True:
+            job = self._in[t].get()
+            if job is None:
+                return
+            fn, chunk = job
+            res = []
+            try:
+                if err is not None:
+                    raise err
+                for idx, item in chunk:
+                    res.append((idx, fn(item, t)))
+                self._out.put((t, res, None))
+            except BaseException as ex:  # noqa: BLE001
+                self._out.put((t, res, ex))
+
+    def map(self, fn, items):
+        items = list(items)
+        chunks = [[(i, items[i]) for i in range(t, len(items), self.nthr)] for t in range(self.nthr)]
+        for t in range(self.nthr):
+            self._in[t].put((fn, chunks[t]))
+        out = [None] * len(items)
+        first = None
+        for _ in range(self.nthr):
+            _, res, ex = self._out.get()
+            for idx, r in res:
+                out[idx] = r
+            if ex is not None and first is None:
+                first = ex
+        if first is not None:
+            raise first
+        return out
+
+    def close(self):
+        for q in self._in:
+            q.put(None)
+        for th in self._threads:
+            th.join(timeout=60)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def run_sharded_batch(n_problems, rank, world, solve, pool):
+    """Solves this rank's share of a batch of independent problems: p -> rank (p mod world), the rank's problems
+    spread over the pool's in-flight workers.  `solve(p, t)` returns the eigenvalues of problem p (a 1-D tensor)
+    computed by worker t.  No communication.  Returns {problem id: eigenvalues}."""
+    mine = shard_problems(n_problems, rank, world)
+    vals = pool.map(solve, mine)
+    return dict(zip(mine, vals))
 
 
 def gather_eigenvalues(local, n_problems, m):
@@ -36,8 +116,7 @@ def gather_eigenvalues(local, n_problems, m):
         return None
     out = torch.zeros((n_problems, m), dtype=torch.float64, device=any_t.device)
     for part in parts:
-        for row in part:
-            p = int(row[0].item())
-            if p >= 0:
-                out[p] = row[1:]
+        ids = part[:, 0].to(torch.int64)
+        keep = ids >= 0
+        out[ids[keep]] = part[keep, 1:]
     return out

@@ -544,6 +544,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
 
 static bool g_use_fast = getenv("EIGSOLVE_GEMM_GENERIC") == nullptr;
 
+// Split-K partial sums live in a per-stream scratch slot: with the two-stream overlap options gemms on c.s1 and c.s2
+// may both take the split path at the same time.
+static const char* splitk_slot(const Ctx& c, hipStream_t st) { return st == c.s2 ? "splitk_s2" : "splitk"; }
+
 template <class T, int BM, int BN>
 static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits) {
     constexpr int BK = (BM * BN <= 64 * 32) ? BKS : BKL;
@@ -654,7 +658,7 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
                     g.kchunk = kchunk;
                     int splits = (K + kchunk - 1) / kchunk;
                     g.pstride = (size_t)M * N;
-                    g.P = c.scratch<T>("splitk", g.pstride * splits);
+                    g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits);
                     dispatch_gemm(c, st, g, splits);
                     size_t total = (size_t)M * N;
                     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N,
@@ -682,7 +686,7 @@ void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Ope
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
     g.kchunk = kchunk;
     g.pstride = (size_t)M * N;
-    g.P = c.scratch<T>("splitk", g.pstride * splits);
+    g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits);
     dispatch_gemm(c, st, g, splits);
     size_t total = (size_t)M * N;
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, splits,

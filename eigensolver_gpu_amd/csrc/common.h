@@ -108,6 +108,8 @@ constexpr int kGstThrDefault = 1024;
 // Order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64 (as produced by the
 // factorization) or 256 (merged after it, build_inv256 in blas3.hip)
 constexpr int kTrsmBaseDefault = 256;
+// Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
+constexpr int kHemvBlocksMax = 8192;
 
 struct Ctx {
     int dev = -1;
@@ -159,5 +161,11 @@ void set_host_threads(int n);
 // roctx (context.cpp)
 void range_push(const char* name);
 void range_pop();
+void phase_range_push(const char* name);   // no device sync (inside the drivers)
+void phase_range_pop();
+struct PhaseRange {
+    explicit PhaseRange(const char* n) { phase_range_push(n); }
+    ~PhaseRange() { phase_range_pop(); }
+};
 
 }  // namespace eig

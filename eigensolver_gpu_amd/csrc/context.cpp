@@ -11,7 +11,18 @@
 namespace eig {
 
 namespace {
-thread_local std::map<int, Ctx*> t_ctx;
+// Contexts are owned by the calling thread: when the thread exits its contexts (streams, events, pinned buffers and the
+// grow-only device scratch, ~1 GB at N=4096 complex) are released with it.
+struct CtxHolder {
+    std::map<int, Ctx*> m;
+    ~CtxHolder() {
+        for (auto& kv : m) {
+            kv.second->release();
+            delete kv.second;
+        }
+    }
+};
+thread_local CtxHolder t_ctx;
 
 std::mutex g_lapack_mu;
 void* g_lapack_handle = nullptr;
@@ -46,6 +57,7 @@ void* Ctx::scratch_bytes(const char* name, size_t bytes) {
     if (s.second < bytes) {
         if (s.first) {
             EIG_HIP(hipStreamSynchronize(s1));
+            EIG_HIP(hipStreamSynchronize(s2));
             EIG_HIP(hipFree(s.first));
         }
         size_t cap = bytes + bytes / 8 + 256;
@@ -67,6 +79,11 @@ void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
 }
 
 void Ctx::release() {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;   // runtime already gone (process teardown): nothing to free
+    if (dev >= 0 && cur != dev) (void)hipSetDevice(dev);
+    if (s1) (void)hipStreamSynchronize(s1);
+    if (s2) (void)hipStreamSynchronize(s2);
     for (auto& kv : graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -86,13 +103,16 @@ void Ctx::release() {
     if (h_info) (void)hipHostFree(h_info);
     if (s1) (void)hipStreamDestroy(s1);
     if (s2) (void)hipStreamDestroy(s2);
+    for (auto& e : ev) e = nullptr;
+    evA = evB = nullptr; d_info = nullptr; h_info = nullptr; s1 = s2 = nullptr;
+    if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);
 }
 
 Ctx& ctx() {
     int dev = 0;
     EIG_HIP(hipGetDevice(&dev));
-    auto it = t_ctx.find(dev);
-    if (it != t_ctx.end()) return *it->second;
+    auto it = t_ctx.m.find(dev);
+    if (it != t_ctx.m.end()) return *it->second;
     Ctx* c = new Ctx();
     c->dev = dev;
     // blocking streams, like the reference's cudaStreamCreate (eigsolve_vars.F90:50-52)
@@ -119,7 +139,8 @@ Ctx& ctx() {
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
     if (c->bt_nb < 1 || c->bt_nb > 128) c->bt_nb = kBtNbDefault;
     if (c->bt_nb > 64) c->bt_nb = 128;
-    t_ctx[dev] = c;
+    if (c->hemv_blocks > kHemvBlocksMax) c->hemv_blocks = kHemvBlocksMax;
+    t_ctx.m[dev] = c;
     return *c;
 }
 
@@ -189,6 +210,17 @@ void range_pop() {
         g_roctx_pop();
     }
 }
+// Phase ranges inside the drivers (the reference wraps potrf/gst/evd/trsm and trd/stedc/unmtr in NVTX ranges,
+// zhegvdx_gpu.F90:134-170, zheevd_gpu.F90:80-132).  No device synchronisation here: they mark the host-side issue
+// window of a phase (several solves may be in flight on one GPU), the per-phase device times are in
+// eigsolve_get_phase_times.
+void phase_range_push(const char* name) {
+    try_roctx();
+    if (g_roctx_push) g_roctx_push(name);
+}
+void phase_range_pop() {
+    if (g_roctx_pop) g_roctx_pop();
+}
 
 }  // namespace eig
 
@@ -206,11 +238,11 @@ int eigsolve_init(void) {
 int eigsolve_finalize(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    auto it = eig::t_ctx.find(dev);
-    if (it == eig::t_ctx.end()) return 0;
+    auto it = eig::t_ctx.m.find(dev);
+    if (it == eig::t_ctx.m.end()) return 0;
     it->second->release();
     delete it->second;
-    eig::t_ctx.erase(it);
+    eig::t_ctx.m.erase(it);
     return 0;
 }
 
@@ -230,7 +262,7 @@ int eigsolve_set_option(const char* name, int value) {
         std::string s(name ? name : "");
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 128) ? eig::kBtNbDefault : (value > 64 ? 128 : value);
-        else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : value;
+        else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
         else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : (value >= 256 ? 256 : 64);

@@ -8,8 +8,23 @@ program test_zhegvdx
   use eigsolve_vars
   use nvtx_inters
   use zhegvdx_gpu
+  use zheevd_gpu
+  use zhegst_gpu
+  use zhetrd_gpu
   use eigsolve_laxlib_glue
   implicit none
+  interface
+    integer(c_int) function eigsolve_zpotrf(N, B, ldb, info) bind(C, name="eigsolve_zpotrf")
+      import :: c_int, c_ptr
+      integer(c_int), value :: N, ldb
+      type(c_ptr), value :: B
+      integer(c_int) :: info
+    end function eigsolve_zpotrf
+  end interface
+  type(c_ptr) :: d_d, e_d, tau_d
+  real(8), allocatable, target :: dh(:), ws(:)
+  integer(c_int) :: pinfo
+  real(8) :: tr
   integer :: N, m, lda, il, iu, info, i, j, k, nargs
   integer :: lwork, lrwork, liwork, lwork_d, lrwork_d
   character(len=32) :: arg
@@ -102,6 +117,49 @@ program test_zhegvdx
   end if
   write(*,*) 'cdiaghg_gpu_glue: eigenvalues identical to the direct call'
   call diaghg_glue_release()
+
+  ! ---- public stage modules with the reference's argument lists (zhegst_gpu.F90:31, zhetrd_gpu.F90:30,
+  ! zheevd_gpu.F90:32-33) ------------------------------------------------------------------------------------
+  call zhegst_gpu(1, 'L', N, A_d, lda, B_d, lda, 448)     ! unsupported: prints and returns (zhegst_gpu.F90:44-47)
+  istat = hipMemcpy(A_d, c_loc(A), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  istat = hipMemcpy(B_d, c_loc(B), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  istat = eigsolve_zpotrf(int(N, c_int), B_d, int(lda, c_int), pinfo)
+  if (istat /= 0 .or. pinfo /= 0) stop 5
+  call zhegst_gpu(1, 'U', N, A_d, lda, B_d, lda, 448)
+  istat = hipMalloc(d_d, int(8, c_size_t) * N)
+  istat = hipMalloc(e_d, int(8, c_size_t) * N)
+  istat = hipMalloc(tau_d, int(16, c_size_t) * N)
+  call zhetrd_gpu('U', N, A_d, lda, d_d, e_d, tau_d, work_d, lwork_d, 32)
+  allocate(dh(N), ws(N))
+  istat = hipMemcpy(c_loc(dh), d_d, int(8, c_size_t) * N, hipMemcpyDeviceToHost)
+  tr = sum(dh)      ! trace(T) = trace(U^-H A U^-1) = sum of all generalized eigenvalues
+  write(*,'(A,2ES22.14)') ' trace(T) after zhegst_gpu + zhetrd_gpu, sum(w): ', tr, sum(wh)
+  if (abs(tr - sum(wh)) > 1.0d-9 * abs(tr)) then
+    write(*,*) 'STAGE TRACE CHECK FAILED'
+    stop 6
+  end if
+  istat = hipMemcpy(A_d, c_loc(A), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  call zheevd_gpu('V', 'U', il, iu, N, A_d, lda, Z_d, lda, w_d, work_d, lwork_d, rwork_d, lrwork_d, &
+                  work, lwork, rwork, lrwork, iwork, liwork, Zh, lda, ws, info)
+  if (info /= 0) stop 7
+  istat = hipMemcpy(c_loc(Zh), Z_d, int(16, c_size_t) * N * N, hipMemcpyDeviceToHost)
+  istat = hipMemcpy(c_loc(ws), w_d, int(8, c_size_t) * N, hipMemcpyDeviceToHost)
+  res = 0
+  do k = 1, m
+    do i = 1, N
+      s = -ws(k) * Zh(i,k)
+      do j = 1, N
+        s = s + A(i,j) * Zh(j,k)
+      end do
+      res = res + abs(s)**2
+    end do
+  end do
+  res = sqrt(res) / sqrt(nrmA)
+  write(*,'(A,ES10.3)') ' zheevd_gpu standard problem residual=', res
+  if (res > N * epsilon(1.0d0)) then
+    write(*,*) 'ZHEEVD RESIDUAL CHECK FAILED'
+    stop 8
+  end if
   write(*,*) 'PASSED'
 
 contains

@@ -77,7 +77,8 @@ int eigsolve_get_phase_times(double *ms, int n);
  * eigenvalues ascending (zheevd_gpu.F90:111), Z_h/w_h host copies (Z_h skipped when
  * skip_host_copy != 0).  Size contract (checked, *info=-1 + message otherwise):
  * lwork >= 2*64*64+65*N, lrwork >= N, lwork_h >= N, lrwork_h >= 1+5*N+2*N*N,
- * liwork_h >= 3+5*N; Z_d and Z_h need N columns.  *info = 0 ok / -1 error (bad workspace,
+ * liwork_h >= 3+5*N when the host dstedc is selected ("tridiag" = 0), >= N otherwise (the reference announces 3+5*N and
+ * rejects only liwork_h < N, zhegvdx_gpu.F90:123); Z_d and Z_h need N columns.  *info = 0 ok / -1 error (bad workspace,
  * B not positive definite, tridiagonal solver failure, copy failure).  Blocking: results
  * are valid on return.  Return value == *info. */
 int eigsolve_zhegvdx(int N, void *A_d, int lda, void *B_d, int ldb, void *Z_d, int ldz, int il, int iu,
@@ -116,6 +117,19 @@ int eigsolve_zhetrd(int N, void *A_d, int lda, double *d_d, double *e_d, void *t
                     int nb);
 int eigsolve_dsytrd(int N, double *A_d, int lda, double *d_d, double *e_d, double *tau_d, double *work_d,
                     int lwork, int nb);
+
+/* zlarft_gpu + finish_T_block_kernel (zheevd_gpu.F90:136-176,215-279; dsyevd_gpu.F90:134-174,212-276) for ALL
+ * reflector blocks of a tridiagonalized A_d (reflector j in column j+1 of upper(A_d), as ?hetrd leaves them, tau_d[N-1]):
+ * block b covers reflectors b*nb .. min((b+1)*nb, N-1)-1, nb = 64 (the reference's larfb width) or 128 (two 64-blocks
+ * whose T factors are merged, T10 = -T1 (V1^H V0) T0).  T_d receives ceil((N-1)/nb) lower-triangular factors, block b
+ * at T_d + b*ldt*ldt with leading dimension ldt >= min(nb, N) rounded up to 64/128.  Stage-level parity hook. */
+int eigsolve_zlarft(int N, const void *A_d, int lda, const void *tau_d, int nb, void *T_d, int ldt);
+int eigsolve_dlarft(int N, const double *A_d, int lda, const double *tau_d, int nb, double *T_d, int ldt);
+
+/* The back-transformation loop of zheevd_gpu.F90:113-131 (zlarft_gpu + zlarfb_gpu per block, i.e. LAPACK
+ * ZUNMTR('L','U','N')): Z_d(0:N, 0:m) <- Q Z_d with Q = H(N-2)...H(0) from the reflectors in upper(A_d). nb as above. */
+int eigsolve_zunmtr(int N, int m, const void *A_d, int lda, const void *tau_d, void *Z_d, int ldz, int nb);
+int eigsolve_dormtr(int N, int m, const double *A_d, int lda, const double *tau_d, double *Z_d, int ldz, int nb);
 
 /* Upper Cholesky B = U^H U (replaces cusolverDn?potrf, zhegvdx_gpu.F90:135).  *info_h = 0
  * or the 1-based index of the first non-positive pivot (LAPACK convention). */

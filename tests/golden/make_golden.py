@@ -27,6 +27,7 @@ CASES = [  # (name, N, complex, family)
     ("d33", 33, False, "ref"), ("z33", 33, True, "ref"),
     ("d64wc", 64, False, "wc"), ("z70wc", 70, True, "wc"),
     ("d96", 96, False, "ref"), ("z96", 96, True, "ref"),
+    ("d256", 256, False, "ref"),   # BASELINE.json configs[0] (C1): dsygvdx N=256, eigenpairs 1..64
 ]
 
 
@@ -53,5 +54,7 @@ def make(name, n, cplx, fam):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for c in CASES:
-        make(*c)
+        if not only or c[0] in only:
+            make(*c)

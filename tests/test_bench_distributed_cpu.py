@@ -1,6 +1,7 @@
-"""world_size-2 gloo test of the batch sharding logic used by bench.py / the multi-GPU path
-(no GPU here): problems are partitioned p -> rank (p mod G) with no data-path collective, the
-only collectives are the timing MAX-reduce and the optional result gather."""
+"""world_size-2 gloo test of the batch path bench.py uses for the multi-GPU legs (no GPU here): the SAME functions --
+batch.shard_problems / InflightPool / run_sharded_batch / gather_eigenvalues -- driven with a CPU stub solver.
+Problems are partitioned p -> rank (p mod G) with no data-path collective; the only collectives are the timing
+all_gather and the result gather."""
 import os
 import subprocess
 import sys
@@ -9,28 +10,53 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = textwrap.dedent("""
-    import os, sys
+    import os, sys, threading
     sys.path.insert(0, %r)
     import torch, torch.distributed as dist
-    from eigensolver_gpu_amd.batch import shard_problems, gather_eigenvalues
+    from eigensolver_gpu_amd.batch import InflightPool, shard_problems, run_sharded_batch, gather_eigenvalues
     dist.init_process_group(backend="gloo")
     r, w = dist.get_rank(), dist.get_world_size()
-    mine = shard_problems(13, r, w)
+    NP, M = 13, 4
+    mine = shard_problems(NP, r, w)
     allp = [None] * w
     dist.all_gather_object(allp, mine)
-    flat = sorted(sum(allp, []))
-    assert flat == list(range(13)), flat
+    assert sorted(sum(allp, [])) == list(range(NP))
     assert all(p %% w == r for p in mine)
-    # result gather: each rank contributes (problem id, eigenvalues)
-    local = {p: torch.arange(4, dtype=torch.float64) + p for p in mine}
-    got = gather_eigenvalues(local, 13, 4)
+
+    def matrix(p):            # problem p: a seeded symmetric matrix whose eigenvalues the stub solver returns
+        g = torch.Generator().manual_seed(1000 + 17 * p)
+        a = torch.rand((8, 8), generator=g, dtype=torch.float64)
+        return a + a.T + 8 * torch.eye(8, dtype=torch.float64)
+
+    seen = {}
+    def init(t):
+        seen[t] = threading.get_ident()
+    def solve(p, t):          # CPU stand-in for api.hegvdx on worker t's context
+        assert threading.get_ident() == seen[t]      # persistent threads: the worker that was initialised
+        return torch.linalg.eigvalsh(matrix(p))[:M]
+
+    with InflightPool(2, init=init) as pool:
+        for step in range(3):                         # same threads across steps (contexts live with them)
+            local = run_sharded_batch(NP, r, w, solve, pool)
+        assert sorted(local) == mine
+        ids = {threading.get_ident()}
+        assert len(seen) == 2 and not (set(seen.values()) & ids)
+        try:                                          # worker exceptions surface in the caller
+            pool.map(lambda p, t: 1 // 0, [1, 2, 3])
+            raise SystemExit("exception was swallowed")
+        except ZeroDivisionError:
+            pass
+    got = gather_eigenvalues(local, NP, M)
     if r == 0:
-        assert got.shape == (13, 4)
-        for p in range(13):
-            assert float(got[p, 0]) == p
+        assert got.shape == (NP, M)
+        for p in range(NP):
+            assert torch.equal(got[p], torch.linalg.eigvalsh(matrix(p))[:M]), p
+    else:
+        assert got is None
     t = torch.tensor([1.0 + r], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    assert float(t) == float(w)
+    allt = [torch.empty_like(t) for _ in range(w)]
+    dist.all_gather(allt, t)
+    assert max(float(x) for x in allt) == float(w)
     dist.barrier()
     dist.destroy_process_group()
     print("rank", r, "ok")
@@ -46,3 +72,10 @@ def test_two_rank_gloo(tmp_path):
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_uses_the_batch_module():
+    """bench.py's multi-GPU legs go through eigensolver_gpu_amd/batch.py (the functions the gloo test drives)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems"):
+        assert name in src
