@@ -875,6 +875,140 @@ __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, i
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// chol_row_kernel: one block row of the right-looking blocked Cholesky (upper), WITHOUT any inverse:
+//     U_kk = chol(B_kk),   U(k, chunk c) = U_kk^-H B(k, chunk c)   for every 64-column chunk c of the block row.
+// Workgroup c owns chunk c (chunk 0 = the diagonal block itself) and carries it through the 64 elimination steps of the
+// diagonal block, which every workgroup repeats on its own copy (64^3/3 multiply-adds: nothing next to a launch and
+// a dependent 64x64 triangular solve).  Row operations applied to [B_kk | B_kc] produce U_kc directly -- the same
+// arithmetic as LAPACK's potf2 on the block row, no explicit inverse of U_kk on the factorization's critical path.
+// Layout as in diag_block_kernel: thread (tr, tc) owns a 2x2 block of the diagonal block and the 2x2 block at the same
+// position of its chunk; one double-buffered LDS broadcast of the pivot row and one barrier per elimination step.
+// ------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info) {
+    __shared__ T rowb[2][DB];   // pivot row of the diagonal block
+    __shared__ T rowp[2][DB];   // pivot row of this workgroup's chunk
+    const int tid = threadIdx.x;
+    const int tr = tid / NTD, tc = tid % NTD;
+    const int chunk = blockIdx.x;
+    const bool has_p = chunk > 0;
+    const int nb = min(DB, n_total - k0);
+    const int c0 = k0 + chunk * DB;                 // first column of the chunk
+    const int pc = min(DB, n_total - c0);
+    T* Dblk = Bm + (size_t)k0 + (size_t)k0 * ldb;
+    T* Pblk = Bm + (size_t)k0 + (size_t)c0 * ldb;
+
+    T u[PB][PB], p[PB][PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int r = PB * tr + i, cc = PB * tc + j;
+            const bool in = r < nb && cc < nb && r <= cc;
+            const T v = Dblk[(size_t)min(r, nb - 1) + (size_t)min(cc, nb - 1) * ldb];
+            u[i][j] = sel(in, v, sel(r == cc, Tr<T>::one(), Tr<T>::zero()));
+            const T w = Pblk[(size_t)min(r, nb - 1) + (size_t)min(cc, pc - 1) * ldb];
+            p[i][j] = sel(has_p && r < nb && cc < pc, w, Tr<T>::zero());
+        }
+
+    const bool upper_blk = tc >= tr;
+    const bool diag_blk = tc == tr;
+    for (int jb = 0; jb < DB / PB; ++jb) {
+#pragma unroll
+        for (int jj = 0; jj < PB; ++jj) {
+            const int j = PB * jb + jj, buf = jj & 1;
+            if (tr == jb) {
+#pragma unroll
+                for (int q = 0; q < PB; ++q) {
+                    rowb[buf][PB * tc + q] = u[jj][q];
+                    rowp[buf][PB * tc + q] = p[jj][q];
+                }
+            }
+            __syncthreads();
+            double d = real_(rowb[buf][j]);
+            if (!(d > 0.0)) {
+                if (tid == 0 && chunk == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
+                d = 1.0;
+            }
+            if (tr >= jb) {   // rows >= j only
+                const double ipiv = fast_rsqrt(d);
+                T ur[PB];
+#pragma unroll
+                for (int q = 0; q < PB; ++q) ur[q] = rowb[buf][PB * tr + q] * ipiv;   // u(j, r) for my rows
+                if (upper_blk) {
+                    double piv = d * ipiv;
+                    piv = fma(fma(-piv, piv, d), 0.5 * ipiv, piv);
+                    T uc[PB];
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) uc[q] = rowb[buf][PB * tc + q] * ipiv;   // u(j, c) for my columns
+                    if (tr > jb) {
+#pragma unroll
+                        for (int i = 0; i < PB; ++i)
+#pragma unroll
+                            for (int q = 0; q < PB; ++q) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], uc[q]);
+                                u[i][q] = u[i][q] - t;
+                            }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PB; ++q) {
+                            if (!diag_blk || q > jj) u[jj][q] = uc[q];
+                            else if (q == jj) u[jj][q] = Tr<T>::make(piv, 0.0);
+                        }
+#pragma unroll
+                        for (int i = jj + 1; i < PB; ++i)
+#pragma unroll
+                            for (int q = 0; q < PB; ++q) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], uc[q]);
+                                u[i][q] = u[i][q] - t;
+                            }
+                    }
+                }
+                if (has_p) {
+                    T pr[PB];
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) pr[q] = rowp[buf][PB * tc + q] * ipiv;   // final U(j, my chunk columns)
+                    if (tr > jb) {
+#pragma unroll
+                        for (int i = 0; i < PB; ++i)
+#pragma unroll
+                            for (int q = 0; q < PB; ++q) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], pr[q]);
+                                p[i][q] = p[i][q] - t;
+                            }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PB; ++q) p[jj][q] = pr[q];
+#pragma unroll
+                        for (int i = jj + 1; i < PB; ++i)
+#pragma unroll
+                            for (int q = 0; q < PB; ++q) {
+                                T t = Tr<T>::zero();
+                                fmac_(t, ur[i], pr[q]);
+                                p[i][q] = p[i][q] - t;
+                            }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int r = PB * tr + i, cc = PB * tc + q;
+            if (!has_p) {
+                if (r < nb && cc < nb && r <= cc) Dblk[(size_t)r + (size_t)cc * ldb] = u[i][q];
+            } else {
+                if (r < nb && cc < pc) Pblk[(size_t)r + (size_t)cc * ldb] = p[i][q];
+            }
+        }
+}
+
 // A_kk <- invU^H * Herm(A_kk) * invU for one diagonal block (upper triangle in/out, real diagonal).
 template <class T>
 __global__ void __launch_bounds__(256) hegs2_block_kernel(int nb, T* Ablk, int lda, const T* inv) {
@@ -1126,13 +1260,34 @@ static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int
     if (use256 && block_root) build_inv256_groups<T>(c, st, Ntot, (const T*)B, ldb, k0 / BB, 1);
 }
 
+template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
+
+// Right-looking blocked Cholesky with block rows of 64: per block row ONE chol_row_kernel launch (diagonal block factored,
+// the whole block row solved, one workgroup per 64-column chunk) and ONE rank-64 MFMA update of the trailing triangle.
+// 2 launches per block row, no inverse and no 64-wide product on the critical path (the recursive form -- potrf_rec,
+// kept for the two-stream option -- spent its time in a chain of 64 one-workgroup factor+invert kernels and ~190 small
+// dependent products: 10.9 ms at C3).  The inverted diagonal blocks the later solves use are formed afterwards, all blocks
+// in parallel.  EIGSOLVE_POTRF=rec / option "potrf" = 0 restores the recursive form.
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
     EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), st));
-    // (merging the inverses block by block inside the recursion was measured: the three small launches per
-    //  256-block sit on the factorization's critical path and cost more than the panel solves gain)
-    potrf_rec(c, st, N, N, 0, B, ldb, invU);
+    if (c.potrf_mode == 0) {
+        potrf_rec(c, st, N, N, 0, B, ldb, invU);
+    } else {
+        for (int k0 = 0; k0 < N; k0 += DB) {
+            const int nb = min(DB, N - k0), rem = N - k0 - nb;
+            hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + (rem + DB - 1) / DB), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info);
+            if (rem > 0) {
+                const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
+                Epi e; e.uplo = 1; e.herm_diag = 1;
+                gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
+                        B + (size_t)(k0 + nb) + (size_t)(k0 + nb) * ldb, ldb, e);
+            }
+        }
+        EIG_HIP(hipGetLastError());
+        build_invU<T>(c, st, N, (const T*)B, ldb);
+    }
     if (c.trsm_base == BB) build_inv256<T>(c, st, N, (const T*)B, ldb);
 }
 

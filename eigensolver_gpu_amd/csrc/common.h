@@ -127,6 +127,7 @@ struct Ctx {
     int trd_nb = 64;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
+    int hemv_balance = 0; // 1: spread the hemv tiles evenly over the rounds (measured slower, see hemv_grid in trd.hip)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
     int overlap = kOverlapDefault;   // bit 0: potrf || first half of gst (uses the symmetric hegst recursion: -3 % latency of an
@@ -139,6 +140,7 @@ struct Ctx {
     };
     std::map<std::string, GraphEntry> graphs;
     int trsm_base = kTrsmBaseDefault;
+    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_kernel + rank-64 updates), 0: recursive (potrf_rec)
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
