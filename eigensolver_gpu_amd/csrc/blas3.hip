@@ -885,8 +885,12 @@ __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, i
 // Layout as in diag_block_kernel: thread (tr, tc) owns a 2x2 block of the diagonal block and the 2x2 block at the same
 // position of its chunk; one double-buffered LDS broadcast of the pivot row and one barrier per elimination step.
 // ------------------------------------------------------------------------------------------------
+// The diagonal block is factored IN PLACE by workgroup 0 while the other workgroups read the original block: workgroup 0
+// only stores U_kk once every other workgroup has announced (one agent-scope atomic on `loaded`, a cumulative counter
+// of the current factorization) that its copy sits in registers.  Nobody waits for workgroup 0, so the spin cannot deadlock.
 template <class T>
-__global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info) {
+__global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info, unsigned* loaded,
+                                                       unsigned expect) {
     __shared__ T rowb[2][DB];   // pivot row of the diagonal block
     __shared__ T rowp[2][DB];   // pivot row of this workgroup's chunk
     const int tid = threadIdx.x;
@@ -911,6 +915,12 @@ __global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int l
             const T w = Pblk[(size_t)min(r, nb - 1) + (size_t)min(cc, pc - 1) * ldb];
             p[i][j] = sel(has_p && r < nb && cc < pc, w, Tr<T>::zero());
         }
+    if (has_p) {
+        // the loads above have landed once their values are consumed; make that explicit, then announce
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     const bool upper_blk = tc >= tr;
     const bool diag_blk = tc == tr;
@@ -995,6 +1005,13 @@ __global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int l
                 }
             }
         }
+    }
+    if (!has_p) {
+        if (tid == 0) {
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i)
@@ -1271,13 +1288,17 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
-    EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), st));
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, 2 * sizeof(int), st));
     if (c.potrf_mode == 0) {
         potrf_rec(c, st, N, N, 0, B, ldb, invU);
     } else {
+        unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 1;   // zeroed with d_info above
+        unsigned expect = 0;
         for (int k0 = 0; k0 < N; k0 += DB) {
             const int nb = min(DB, N - k0), rem = N - k0 - nb;
-            hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + (rem + DB - 1) / DB), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info);
+            const int chunks = (rem + DB - 1) / DB;
+            expect += (unsigned)chunks;
+            hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
             if (rem > 0) {
                 const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
                 Epi e; e.uplo = 1; e.herm_diag = 1;
