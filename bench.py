@@ -96,8 +96,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["c3", "c5"], default="c3")
-    ap.add_argument("--n", type=int, default=0, help="override the order (default: 4096 for c3, 2048 for c5)")
-    ap.add_argument("--m", type=int, default=0, help="override the number of eigenpairs (default: n/4)")
+    ap.add_argument("--n", "--order", dest="n", type=int, default=0, help="override the order (default: 4096 for c3, 2048 for c5)")
+    ap.add_argument("--m", "--pairs", dest="m", type=int, default=0, help="override the number of eigenpairs (default: n/4)")
     ap.add_argument("--real", action="store_true", help="dsygvdx instead of zhegvdx")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--tridiag", choices=["device", "host"], default="device",
                     help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
     ap.add_argument("--log-steps", action="store_true", help="add per-step wall ms to the line")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "single-GPU self-test of the multi-rank path, see --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses GPU 0 (multi-rank logic on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np  # noqa: F401
@@ -122,11 +125,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
     cplx = not args.real
     c5 = args.workload == "c5"
     n = args.n or (2048 if c5 else 4096)

@@ -83,6 +83,8 @@ template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* 
 template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X(mxn) <- X U^-1
 // merged 256x256 inverse diagonal blocks for base = 256 (needs the 64-block inverses of potrf_upper / build_invU)
 template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
+// all merged inverse blocks the "trsm_base" option asks for (256, 512, 1024), from the 64-block inverses
+template <class T> void build_inv_blocks(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
 
 // A <- U^-H A U^-1 (upper triangle only is read/written).
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);

@@ -15,6 +15,8 @@
 //  * triangular / unit-trapezoid masks, conjugation, K-concatenation (her2k in one pass over
 //    C) and triangular-output filtering are folded into the operand loader / epilogue, so no
 //    operand is ever physically modified (the reference stashes/zeros/restores blocks of A).
+#include <type_traits>
+
 #include "blas3.h"
 #include "lanes.h"
 
@@ -924,86 +926,83 @@ __global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int l
 
     const bool upper_blk = tc >= tr;
     const bool diag_blk = tc == tr;
+    static_assert(PB == 2, "the look-ahead schedule below is written for 2x2 register blocks");
+    // Row j is scaled by its owners (the 32 threads of block row j/2: one half wave, the pivot comes from the diagonal
+    // thread by v_readlane) BEFORE it is broadcast, and it is published one step ahead: right after the barrier of step j
+    // the owners of row j+1 update only that row, take the reciprocal square root, scale and write the row to the other
+    // LDS buffer, and only then do their share of the bulk update -- the rsqrt chain of the next pivot overlaps with the
+    // rank-1 update of everybody else, and nobody but the owners evaluates it.
+    auto publish = [&](auto JJ, int jbn, int bufn) {
+        constexpr int jj = decltype(JJ)::value;
+        double dd = read_lane(real_(u[jj][jj]), (jbn & 1) * 32 + jbn);   // u(j,j) of the diagonal thread (tc == tr == jbn)
+        const int j = PB * jbn + jj;
+        if (!(dd > 0.0)) {
+            if (diag_blk && chunk == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
+            dd = 1.0;
+        }
+        const double ipiv = fast_rsqrt(dd);
+        double piv = dd * ipiv;
+        piv = fma(fma(-piv, piv, dd), 0.5 * ipiv, piv);
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            u[jj][q] = (diag_blk && q == jj) ? Tr<T>::make(piv, 0.0) : u[jj][q] * ipiv;
+            p[jj][q] = p[jj][q] * ipiv;
+            rowb[bufn][PB * tc + q] = u[jj][q];
+            rowp[bufn][PB * tc + q] = p[jj][q];
+        }
+    };
+    // rank-1 update of local row i with the scaled pivot row (ur = u(j, my row i), uc / pr = u(j, my columns))
+    auto upd_row = [&](auto II, const T (&ur)[PB], const T (&uc)[PB], const T (&pr)[PB]) {
+        constexpr int i = decltype(II)::value;
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            if (upper_blk) {
+                T t = Tr<T>::zero();
+                fmac_(t, ur[i], uc[q]);
+                u[i][q] = u[i][q] - t;
+            }
+            if (has_p) {
+                T t = Tr<T>::zero();
+                fmac_(t, ur[i], pr[q]);
+                p[i][q] = p[i][q] - t;
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (tr == 0) publish(I0{}, 0, 0);
     for (int jb = 0; jb < DB / PB; ++jb) {
+        // ---- step j = 2 jb (local row 0 of block row jb is the pivot row) ----
+        __syncthreads();
+        if (tr >= jb) {
+            T ur[PB], uc[PB], pr[PB];
 #pragma unroll
-        for (int jj = 0; jj < PB; ++jj) {
-            const int j = PB * jb + jj, buf = jj & 1;
+            for (int q = 0; q < PB; ++q) {
+                ur[q] = rowb[0][PB * tr + q];
+                uc[q] = rowb[0][PB * tc + q];
+                pr[q] = rowp[0][PB * tc + q];
+            }
             if (tr == jb) {
-#pragma unroll
-                for (int q = 0; q < PB; ++q) {
-                    rowb[buf][PB * tc + q] = u[jj][q];
-                    rowp[buf][PB * tc + q] = p[jj][q];
-                }
+                upd_row(I1{}, ur, uc, pr);       // the next pivot row first ...
+                publish(I1{}, jb, 1);            // ... scaled and published one step ahead
+            } else {
+                upd_row(I0{}, ur, uc, pr);
+                upd_row(I1{}, ur, uc, pr);
             }
-            __syncthreads();
-            double d = real_(rowb[buf][j]);
-            if (!(d > 0.0)) {
-                if (tid == 0 && chunk == 0 && j < nb) atomicCAS(info, 0, k0 + j + 1);
-                d = 1.0;
+        }
+        // ---- step j = 2 jb + 1 (local row 1 is the pivot row; the next one is local row 0 of block row jb + 1) ----
+        __syncthreads();
+        if (tr > jb) {
+            T ur[PB], uc[PB], pr[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                ur[q] = rowb[1][PB * tr + q];
+                uc[q] = rowb[1][PB * tc + q];
+                pr[q] = rowp[1][PB * tc + q];
             }
-            if (tr >= jb) {   // rows >= j only
-                const double ipiv = fast_rsqrt(d);
-                T ur[PB];
-#pragma unroll
-                for (int q = 0; q < PB; ++q) ur[q] = rowb[buf][PB * tr + q] * ipiv;   // u(j, r) for my rows
-                if (upper_blk) {
-                    double piv = d * ipiv;
-                    piv = fma(fma(-piv, piv, d), 0.5 * ipiv, piv);
-                    T uc[PB];
-#pragma unroll
-                    for (int q = 0; q < PB; ++q) uc[q] = rowb[buf][PB * tc + q] * ipiv;   // u(j, c) for my columns
-                    if (tr > jb) {
-#pragma unroll
-                        for (int i = 0; i < PB; ++i)
-#pragma unroll
-                            for (int q = 0; q < PB; ++q) {
-                                T t = Tr<T>::zero();
-                                fmac_(t, ur[i], uc[q]);
-                                u[i][q] = u[i][q] - t;
-                            }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < PB; ++q) {
-                            if (!diag_blk || q > jj) u[jj][q] = uc[q];
-                            else if (q == jj) u[jj][q] = Tr<T>::make(piv, 0.0);
-                        }
-#pragma unroll
-                        for (int i = jj + 1; i < PB; ++i)
-#pragma unroll
-                            for (int q = 0; q < PB; ++q) {
-                                T t = Tr<T>::zero();
-                                fmac_(t, ur[i], uc[q]);
-                                u[i][q] = u[i][q] - t;
-                            }
-                    }
-                }
-                if (has_p) {
-                    T pr[PB];
-#pragma unroll
-                    for (int q = 0; q < PB; ++q) pr[q] = rowp[buf][PB * tc + q] * ipiv;   // final U(j, my chunk columns)
-                    if (tr > jb) {
-#pragma unroll
-                        for (int i = 0; i < PB; ++i)
-#pragma unroll
-                            for (int q = 0; q < PB; ++q) {
-                                T t = Tr<T>::zero();
-                                fmac_(t, ur[i], pr[q]);
-                                p[i][q] = p[i][q] - t;
-                            }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < PB; ++q) p[jj][q] = pr[q];
-#pragma unroll
-                        for (int i = jj + 1; i < PB; ++i)
-#pragma unroll
-                            for (int q = 0; q < PB; ++q) {
-                                T t = Tr<T>::zero();
-                                fmac_(t, ur[i], pr[q]);
-                                p[i][q] = p[i][q] - t;
-                            }
-                    }
-                }
-            }
+            upd_row(I0{}, ur, uc, pr);
+            if (tr == jb + 1) publish(I0{}, jb + 1, 0);
+            upd_row(I1{}, ur, uc, pr);
         }
     }
     if (!has_p) {
@@ -1178,6 +1177,70 @@ template <class T> static Operand<T> op_inv256(Ctx& c, int k0, int trans, int co
     o.p = c.scratch<T>("invU256", 0) + (size_t)(k0 / BB) * BB * BB; o.ld = BB; o.trans = trans; o.conj = conj; o.mask = M_UPPER;
     return o;
 }
+
+// ---- inverse diagonal blocks of order 512 / 1024 (option "trsm_base") ------------------------------------------------
+// One more level (or two) of the same merge, inv([[U0, M], [0, U1]]) = [[I0, -I0 M I1], [0, I1]], this time as MFMA
+// products (K-trimmed triangular operands): the solves of hegst and the final trsm then stop at 512/1024-blocks -- a
+// quarter / a sixteenth of the dependent launches of the 256-block form.  tools/inverse_vs_substitution.py: residual and
+// B-orthonormality on the reference recipe (cond(B) 1.5e10) are the same for substitution and for inverse blocks of any
+// order up to the whole factor.
+static inline int norm_base(int base) { return base >= 1024 ? 1024 : (base >= 512 ? 512 : (base >= 256 ? 256 : 64)); }
+static const char* big_slot(int base) { return base == 1024 ? "invU1024" : "invU512"; }
+
+template <class T> static Operand<T> op_invbig(Ctx& c, int base, int k0, int trans, int conj) {
+    if (base == BB) return op_inv256<T>(c, k0, trans, conj);
+    Operand<T> o;
+    o.p = c.scratch<T>(big_slot(base), 0) + (size_t)(k0 / base) * base * base; o.ld = base; o.trans = trans; o.conj = conj;
+    o.mask = M_UPPER;
+    return o;
+}
+
+// diagonal sub-blocks of order `sub` (from the slot of that order, ld = sub) -> diagonal positions of the groups of order
+// `big`; identity where the matrix has ended
+template <class T>
+__global__ void __launch_bounds__(256) place_inv_kernel(int N, int sub, int big, const T* src, T* dst) {
+    const int per = big / sub, slot = blockIdx.y;                 // sub-block index over the whole matrix
+    T* G = dst + (size_t)(slot / per) * big * big + (size_t)(slot % per) * sub * (1 + big);
+    const bool have = slot * sub < N;
+    const T* S = src + (size_t)slot * sub * sub;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)sub * sub; e += (size_t)gridDim.x * 256) {
+        const int r = (int)(e % sub), cc = (int)(e / sub);
+        G[(size_t)r + (size_t)cc * big] = have ? S[e] : ((r == cc) ? Tr<T>::one() : Tr<T>::zero());
+    }
+}
+
+// inv blocks of order `big` from those of order big/2 (which must exist: 256 from build_inv256, 512 from this routine)
+template <class T> static void build_inv_level(Ctx& c, hipStream_t st, int N, const T* U, int ldu, int big) {
+    const int sub = big / 2, ng = (N + big - 1) / big;
+    const T* src = sub == BB ? c.scratch<T>("invU256", 0) : c.scratch<T>(big_slot(sub), 0);
+    T* dst = c.scratch<T>(big_slot(big), (size_t)ng * big * big);
+    EIG_HIP(hipMemsetAsync(dst, 0, sizeof(T) * (size_t)ng * big * big, st));
+    hipLaunchKernelGGL((place_inv_kernel<T>), dim3(64, ng * 2), dim3(256), 0, st, N, sub, big, src, dst);
+    T* tmp = c.scratch<T>("inv_tmp", (size_t)sub * sub);
+    for (int g = 0; g < ng; ++g) {
+        const int k = g * big;
+        const int n0 = min(sub, N - k), n1 = min(sub, N - (k + sub));
+        if (n1 <= 0) continue;
+        T* G = dst + (size_t)g * big * big;
+        Operand<T> I0 = op_plain((const T*)G, big, 0, 0);                                   // A operand (rows x k)
+        I0.mask = M_UPPER;
+        Operand<T> I1 = op_plain((const T*)(G + (size_t)sub * (1 + big)), big, 1, 0);        // B operand 'N': Bt(j,k) = I1(k,j)
+        I1.mask = M_UPPER;
+        const T* M = U + (size_t)k + (size_t)(k + sub) * ldu;
+        gemm<T>(c, st, n0, n1, n1, Tr<T>::one(), opA('N', M, ldu), I1, Tr<T>::zero(), tmp, sub);             // tmp = M I1
+        gemm<T>(c, st, n0, n1, n0, Tr<T>::make(-1.0, 0.0), I0, opB('N', (const T*)tmp, sub), Tr<T>::zero(),
+                G + (size_t)sub * big, big);                                                                   // P = -I0 tmp
+    }
+    EIG_HIP(hipGetLastError());
+}
+
+// everything the solves outside potrf need beyond the 64-block inverses, per the "trsm_base" option
+template <class T> void build_inv_blocks(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
+    const int base = norm_base(c.trsm_base);
+    if (base >= BB) build_inv256<T>(c, st, N, U, ldu);
+    if (base >= 512) build_inv_level<T>(c, st, N, U, ldu, 512);
+    if (base >= 1024) build_inv_level<T>(c, st, N, U, ldu, 1024);
+}
 // result of a 256-base product goes through scratch (row blocks of the result are other workgroups' operands)
 template <class T> static void copy_back(hipStream_t st, const T* tmp, int ldt, T* X, int ldx, int rows, int cols) {
     EIG_HIP(hipMemcpy2DAsync(X, sizeof(T) * ldx, tmp, sizeof(T) * ldt, sizeof(T) * rows, cols, hipMemcpyDeviceToDevice, st));
@@ -1186,15 +1249,15 @@ template <class T> static void copy_back(hipStream_t st, const T* tmp, int ldt, 
 template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
-    if (base != BB) base = DB;
+    base = norm_base(base);
     if (n <= base) {
         if (base == DB) {
             Epi e; e.inplace = 1;
             gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
                     Tr<T>::zero(), X, ldx, e);
         } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv256<T>(c, k0, 0, 0), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbig<T>(c, base, k0, 0, 0), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
             copy_back(st, tmp, n, X, ldx, n, m);
         }
         return;
@@ -1209,15 +1272,15 @@ template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* 
 template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
-    if (base != BB) base = DB;
+    base = norm_base(base);
     if (n <= base) {
         if (base == DB) {
             Epi e; e.inplace = 1;
             gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
                     Tr<T>::zero(), X, ldx, e);
         } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv256<T>(c, k0, 1, 1), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
+            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbig<T>(c, base, k0, 1, 1), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
             copy_back(st, tmp, n, X, ldx, n, m);
         }
         return;
@@ -1233,15 +1296,15 @@ template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* 
 template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
     if (n <= 0 || m <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
-    if (base != BB) base = DB;
+    base = norm_base(base);
     if (n <= base) {
         if (base == DB) {
             Epi e; e.inplace = 2;
             gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
                     Tr<T>::zero(), X, ldx, e);
         } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)BB * m);
-            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv256<T>(c, k0, 1, 0), Tr<T>::zero(), tmp, m);
+            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
+            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_invbig<T>(c, base, k0, 1, 0), Tr<T>::zero(), tmp, m);
             copy_back(st, tmp, m, X, ldx, m, n);
         }
         return;
@@ -1309,7 +1372,7 @@ template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb
         EIG_HIP(hipGetLastError());
         build_invU<T>(c, st, N, (const T*)B, ldb);
     }
-    if (c.trsm_base == BB) build_inv256<T>(c, st, N, (const T*)B, ldb);
+    build_inv_blocks<T>(c, st, N, (const T*)B, ldb);
 }
 
 template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
@@ -1366,6 +1429,7 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
 template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr);
+template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
     // EIGSOLVE_GST: 0 = symmetric recursion down to 64x64 blocks (2/3 N^3 multiply-adds, ~16N/64 small launches),
@@ -1375,6 +1439,7 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     //                   <= EIGSOLVE_GST_THR (1024).  C3 (N=4096): 28.3 / 14.2 / 11.0 ms with the 256-block inverses.
     const int mode = c.gst_mode, thr = c.gst_thr;   // EIGSOLVE_GST / EIGSOLVE_GST_THR, eigsolve_set_option("gst" / "gst_thr")
     if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
+    else if (mode == 3) hegst_blocked(c, st, N, A, lda, U, ldu);
     else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
     else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr);
 }
@@ -1432,11 +1497,12 @@ template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, in
 // operation is a large MFMA launch.  Diagonal blocks of order <= thr fall back to the two-solve form.
 template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr) {
     if (n <= 0) return;
-    if (n <= thr) {
+    const int gran = norm_base(c.trsm_base);
+    if (n <= thr || n <= gran) {
         hegst_two_solves_at(c, st, n, k0, A, lda, U, ldu);
         return;
     }
-    int n1 = split_n1(n, c.trsm_base), n2 = n - n1;   // block boundaries must match the inverse diagonal blocks
+    int n1 = split_n1(n, gran), n2 = n - n1;   // block boundaries must match the inverse diagonal blocks
     hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr);
     T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
     T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
@@ -1464,6 +1530,39 @@ template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k
     hemm_half();
     trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda, c.trsm_base);  // A12 <- A12 U22^-1
     hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr);
+}
+
+// The reference's own loop (zhegst_gpu.F90:51-107) with block size nb = the order of the inverse diagonal blocks
+// ("trsm_base" 512 / 1024): per block step the diagonal block by two products with its inverse, then
+// trsm / hemm / her2k / hemm / trsm on the block row -- (1/2 + O(nb/N)) N^3 multiply-adds instead of the ~2/3 N^3 of
+// the half-split recursion.
+template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+    const int base = norm_base(c.trsm_base), nb = base < 256 ? 256 : base;
+    const T mhalf = Tr<T>::make(-0.5, 0.0);
+    for (int k0 = 0; k0 < N; k0 += nb) {
+        const int kb = min(nb, N - k0), rest = N - k0 - kb;
+        hegst_two_solves_at(c, st, kb, k0, A, lda, U, ldu);                          // :57-83
+        if (rest <= 0) break;
+        T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
+        T* A12 = A + (size_t)k0 + (size_t)(k0 + kb) * lda;
+        T* A22 = A + (size_t)(k0 + kb) + (size_t)(k0 + kb) * lda;
+        const T* U12 = U + (size_t)k0 + (size_t)(k0 + kb) * ldu;
+        trsm_LUC(c, st, kb, rest, U, ldu, k0, A12, lda, base);                       // :87-88
+        T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)kb * kb);
+        const int nb32 = (kb + 31) / 32;
+        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, kb, (const T*)A11, lda, H, kb);
+        gemm<T>(c, st, kb, rest, kb, mhalf, opA('N', (const T*)H, kb), opB('N', U12, ldu), Tr<T>::one(), A12, lda);   // :93-94
+        {
+            Operand<T> Ao, Bo;                                                       // :95-96
+            Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = kb; Ao.p2 = U12; Ao.ld2 = ldu;
+            Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = kb; Bo.p2 = A12; Bo.ld2 = lda;
+            Epi e; e.uplo = 1; e.herm_diag = 1;
+            gemm<T>(c, st, rest, rest, 2 * kb, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+        }
+        gemm<T>(c, st, kb, rest, kb, mhalf, opA('N', (const T*)H, kb), opB('N', U12, ldu), Tr<T>::one(), A12, lda);   // :100-101
+        trsm_RUN(c, st, rest, kb, U, ldu, k0 + kb, A12, lda, base);                  // :103-104
+    }
+    EIG_HIP(hipGetLastError());
 }
 
 template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
@@ -1536,6 +1635,7 @@ template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* 
     template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
     template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
     template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \
+    template void build_inv_blocks<T>(Ctx&, hipStream_t, int, const T*, int);                                            \
     template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \
     template void potrf_hegst_overlapped<T>(Ctx&, int, T*, int, T*, int);
 INST(double)

@@ -108,6 +108,7 @@ constexpr int kGstThrDefault = 1024;
 // Order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64 (as produced by the
 // factorization) or 256 (merged after it, build_inv256 in blas3.hip)
 constexpr int kTrsmBaseDefault = 256;
+inline int norm_trsm_base(int v) { return v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 64)); }
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;
 
@@ -127,6 +128,7 @@ struct Ctx {
     int trd_nb = 64;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
+    int p_wt = 0;         // 1: hemv partials stored write-through (sc1), see store_partial in trd.hip
     int hemv_balance = 0; // 1: spread the hemv tiles evenly over the rounds (measured slower, see hemv_grid in trd.hip)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default

@@ -128,14 +128,15 @@ Ctx& ctx() {
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c->trd_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_P_WT")) c->p_wt = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c->hemv_balance = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_GRAPH")) c->use_graph = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) & 3;
-    if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c->trsm_base = atoi(e) >= 256 ? 256 : 64;
+    if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c->trsm_base = norm_trsm_base(atoi(e));
     if (const char* e = getenv("EIGSOLVE_POTRF")) c->potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : 1;
     if (const char* e = getenv("EIGSOLVE_GST")) c->gst_mode = atoi(e);
     if (const char* e = getenv("EIGSOLVE_GST_THR")) c->gst_thr = atoi(e);
-    if (c->gst_mode < 0 || c->gst_mode > 2) c->gst_mode = kGstModeDefault;
+    if (c->gst_mode < 0 || c->gst_mode > 3) c->gst_mode = kGstModeDefault;
     if (c->gst_thr < 256) c->gst_thr = 256;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
@@ -266,11 +267,12 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 128) ? eig::kBtNbDefault : (value > 64 ? 128 : value);
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
         else if (s == "hemv_balance") c.hemv_balance = value != 0;
+        else if (s == "p_wt") c.p_wt = value != 0;
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
-        else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : (value >= 256 ? 256 : 64);
+        else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : eig::norm_trsm_base(value);
         else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
-        else if (s == "gst") c.gst_mode = (value < 0 || value > 2) ? eig::kGstModeDefault : value;
+        else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? eig::kGstModeDefault : value;
         else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;

@@ -364,7 +364,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
             return -1;
         }
         pt.begin(PH_GST);
-        if (c.trsm_base == 256) build_inv256<T>(c, st, N, (const T*)B, ldb);   // for the final trsm
+        build_inv_blocks<T>(c, st, N, (const T*)B, ldb);   // for the final trsm
         pt.end(PH_GST);
     } else {
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
@@ -549,7 +549,7 @@ int eigsolve_zhegst(int N, void* A_d, int lda, const void* B_d, int ldb, int nb)
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
-        if (c.trsm_base == 256) build_inv256<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
+        build_inv_blocks<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
         hegst_upper<cplx>(c, c.s1, N, (cplx*)A_d, lda, (const cplx*)B_d, ldb);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;
@@ -560,7 +560,7 @@ int eigsolve_dsygst(int N, double* A_d, int lda, const double* B_d, int ldb, int
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<double>(c, c.s1, N, B_d, ldb);
-        if (c.trsm_base == 256) build_inv256<double>(c, c.s1, N, B_d, ldb);
+        build_inv_blocks<double>(c, c.s1, N, B_d, ldb);
         hegst_upper<double>(c, c.s1, N, A_d, lda, B_d, ldb);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;
@@ -693,7 +693,7 @@ template <class T> static int trsm_entry(int N, int m, const T* U, int ldu, T* Z
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         build_invU<T>(c, c.s1, N, U, ldu);
-        if (c.trsm_base == 256) build_inv256<T>(c, c.s1, N, U, ldu);
+        build_inv_blocks<T>(c, c.s1, N, U, ldu);
         trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz, c.trsm_base);
         EIG_HIP(hipStreamSynchronize(c.s1));
         return 0;

@@ -58,7 +58,26 @@ template <class T> struct PanelArgs {
     int nblkA;         // norm partials (one per row-kernel wave) produced for column i
     int gh;            // hemv workgroups used for the column being finished / generated
     int nchunk;        // gemv row chunks for that column
+    int wt;            // 1: the hemv partials are stored write-through (sc1), see store_partial
 };
+
+// The hemv partials P (up to nt*n*s bytes = 4 MB at n = 4096) are the only sizeable data the mat-vec kernel writes, and
+// the next kernel (on other XCDs) reads all of it.  A plain store leaves the lines dirty in this XCD's L2 and the kernel
+// boundary pays for their write-back (MI355X_MICROARCH.md, row "boundary": + B / 6 TB/s); an sc1 store writes through
+// while the kernel is still streaming.
+__device__ __forceinline__ void store_partial(cplx* p, cplx v, int wt) {
+    if (wt) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 t = {v.x, v.y};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+    } else {
+        *p = v;
+    }
+}
+__device__ __forceinline__ void store_partial(double* p, double v, int wt) {
+    if (wt) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
 
 // larfg scalars with the reference's scaling (zhetrd_gpu.F90:275-311: scale by max(|ar|,|ai|,xnorm), no
 // safe-minimum loop).  Degenerate case follows LAPACK (tau=0, beta=ar).  This sits on the critical path of
@@ -498,12 +517,12 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelArgs<T> a, int pl
         T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
         if (diag) {
             T s = yv + tv;
-            a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
+            store_partial(&a.P[(size_t)Jc * a.ldp + r0 + lane], s, a.wt);
             fmac_(Sacc, vI, s);
             if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
         } else {
-            a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
-            a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
+            store_partial(&a.P[(size_t)Jc * a.ldp + r0 + lane], yv, a.wt);
+            store_partial(&a.P[(size_t)Ic * a.ldp + c0 + lane], tv, a.wt);
             fmac_(Sacc, vI, yv);
             fmac_(Sacc, vJ, tv);
         }
@@ -656,6 +675,7 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
     PanelArgs<T> a;
     a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = e; a.tau = tau;
     a.xbuf = sc.xbuf; a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp; a.NP = sc.NP; a.alphaSlot = sc.alphaSlot;
+    a.wt = c.p_wt;
     int gh_prev = 0, nchunk_prev = 0;
     for (int i = np - 1; i >= np - nb - 1; --i) {
         const bool last = (i == np - nb - 1);  // finish-only pass for the panel's leftmost column
@@ -741,7 +761,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     PanelArgs<T> a;
     a.A = const_cast<T*>(A); a.lda = lda; a.W = nullptr; a.ldw = 0; a.np = n + 1; a.nb = 1; a.i = n;
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
-    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
+    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0; a.wt = c.p_wt;
     a.gh = hemv_grid(c, n);
     hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(MVT), 0, st, a, 1, 0);
     if (gather) {

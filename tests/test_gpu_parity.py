@@ -167,6 +167,27 @@ def test_potrf_reports_first_bad_pivot(env, cplx):
     assert info == io == 101
 
 
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("base", [64, 256, 512, 1024])
+@pytest.mark.parametrize("n", [300, 1333])
+def test_trsm_inverse_block_orders(env, cplx, base, n):
+    """Z <- U^-1 Z through inverted diagonal blocks of every supported order (merged on MFMA from the 64-block inverses),
+    ragged orders included, against a triangular solve by substitution (numpy/LAPACK)."""
+    torch, oracle, api = env
+    import scipy.linalg as sl
+    B = oracle.gen_spd_fast(n, 2600 + n, cplx, shift=float(n))
+    U = np.linalg.cholesky(B).conj().T
+    rng = np.random.default_rng(n + base)
+    Z = rnd(rng, cplx, n, 97)
+    try:
+        api.set_option("trsm_base", base)
+        Zd = api.to_device(Z)
+        api.trsm_lun(api.to_device(np.triu(U)), Zd, Z.shape[1])
+    finally:
+        api.set_option("trsm_base", 0)
+    assert rel(api.to_host(Zd), sl.solve_triangular(U, Z, lower=False)) <= 1e3 * n * EPS
+
+
 def test_potrf_block_rows_under_concurrent_load(env):
     """chol_row_kernel factors the diagonal block in place while the other workgroups of the launch read it: with several
     factorizations in flight on one GPU (late-starting workgroups) the results must still be those of a quiet run."""
@@ -588,7 +609,9 @@ def test_algorithm_options_agree(env, cplx):
     try:
         for key, opts in (("default", {}), ("gst0", {"gst": 0}), ("gst1", {"gst": 1}), ("gst2", {"gst": 2, "gst_thr": 256}),
                           ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128}), ("tb64", {"trsm_base": 64}),
-                          ("tb256_gst2", {"trsm_base": 256, "gst": 2, "gst_thr": 256})):
+                          ("tb256_gst2", {"trsm_base": 256, "gst": 2, "gst_thr": 256}),
+                          ("tb512", {"trsm_base": 512}), ("tb1024_gst2", {"trsm_base": 1024, "gst": 2, "gst_thr": 256}),
+                          ("potrf_rec", {"potrf": 0})):
             for k, v in opts.items():
                 assert api.set_option(k, v) == 0
             info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
@@ -596,10 +619,11 @@ def test_algorithm_options_agree(env, cplx):
             assert oracle.residual(A, B, w, Z) <= n * EPS
             res[key] = (w, Z)
             for k in opts:
-                api.set_option(k, -1 if k == "gst" else 0)
+                api.set_option(k, -1 if k == "gst" else (1 if k == "potrf" else 0))
     finally:
         for k in ("gst", "gst_thr", "bt_nb", "trsm_base"):
             api.set_option(k, -1 if k == "gst" else 0)
+        api.set_option("potrf", 1)
     w0, Z0 = res["default"]
     for key, (w, Z) in res.items():
         assert oracle.compare_1d(w0, w)[0] <= 1e-13, key
@@ -1004,8 +1028,8 @@ def test_larft_and_backtransform_vs_oracle(env, cplx, n, nb):
 
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n", [300, 1100])
-@pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("base", [64, 256])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("base", [64, 256, 512, 1024])
 def test_hegst_every_branch_vs_oracle(env, cplx, n, mode, base):
     """zhegst_gpu / dsygst_gpu (zhegst_gpu.F90:51-107): the symmetric recursion (gst=0), the two-solve form (gst=1) and
     the hybrid (gst=2, gst_thr=256 so that n=300 and n=1100 take the symmetric step at the top and two solves below) --
@@ -1143,3 +1167,27 @@ def test_fortran_real_driver_random_and_file_input(env, tmp_path):
     w3 = np.array([float(x) for x in line.split(":")[1].split()])
     info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
     assert info == 0 and np.abs(w3 - w[:3]).max() <= 1e-12 * np.abs(w[:3]).max()
+
+
+def test_bench_multi_rank_path_on_one_gpu(env):
+    """bench.py under torchrun with 2 ranks (both on GPU 0, gloo for the collectives -- RCCL refuses two ranks on one
+    device): the multi-rank code path the driver runs on 2/4/8 GPUs -- sharding p -> rank (p mod G), per-rank persistent
+    in-flight workers, max-over-ranks timing, the C5 sharded batch and the eigenvalue gather -- at a small order."""
+    import json
+    import subprocess
+    import sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--order", "512",
+           "--share-gpu", "--backend", "gloo", "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag", "--inflight", "2",
+           "--batch", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["problems_per_step_total"] == 4 and d["config"]["problems_per_gpu_per_step"] == 2
+    assert d["eigenvalues_gathered"] == [4, 128]
+    assert d["residual"] < 1e-9
+    assert d["c5"]["gathered_eigenvalues_shape"] == [64, 512] and d["c5"]["problems_per_gpu"] == 32
+    assert d["c5"]["rerun_bit_identical"] is True
