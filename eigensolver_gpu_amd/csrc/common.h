@@ -44,6 +44,12 @@ __host__ __device__ inline void fma_(cplx& a, cplx b, cplx c) {
     a.x = fma(b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
     a.y = fma(b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
 }
+// a -= conj(b)*c
+__host__ __device__ inline void fmsc_(double& a, double b, double c) { a = fma(-b, c, a); }
+__host__ __device__ inline void fmsc_(cplx& a, cplx b, cplx c) {
+    a.x = fma(-b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
+    a.y = fma(-b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
+}
 // a += conj(b)*c
 __host__ __device__ inline void fmac_(double& a, double b, double c) { a = fma(b, c, a); }
 __host__ __device__ inline void fmac_(cplx& a, cplx b, cplx c) {
@@ -142,7 +148,8 @@ struct Ctx {
     };
     std::map<std::string, GraphEntry> graphs;
     int trsm_base = kTrsmBaseDefault;
-    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_kernel + rank-64 updates), 0: recursive (potrf_rec)
+    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_cyc_kernel + rank-64 updates), 2: the same with the 2x2 /
+                             // 1024-thread block-row kernel, 0: recursive (potrf_rec)
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
