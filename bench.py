@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--tridiag", choices=["device", "host"], default="device",
                     help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
     ap.add_argument("--log-steps", action="store_true", help="add per-step wall ms to the line")
+    ap.add_argument("--same-problems", action="store_true", help="every step re-solves the problems of step 0 (at N=8192 the "
+                    "reference recipe is numerically singular for some seeds -- cond(B) ~ 1e13 -- and Cholesky fails, as LAPACK's does)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU self-test of the multi-rank path, see --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses GPU 0 (multi-rank logic on a 1-GPU box)")
@@ -175,7 +177,7 @@ def main():
     staged = {}
     for s in range(W + K):
         for p in mine:
-            staged[(s, p)] = gen_pair(n, cplx, problem_seed(cfg_index, p, s), dev)
+            staged[(s, p)] = gen_pair(n, cplx, problem_seed(cfg_index, p, 0 if args.same_problems else s), dev)
     for t in range(nthr):
         workspace(t, n)
     torch.cuda.synchronize()
@@ -254,7 +256,7 @@ def main():
     # ---- validity: residual of worker 0's last solve against its pristine inputs (outside the timed region) -------
     resid = berr = bortho = None
     if "p" in last:
-        Ap, Bp = gen_pair(n, cplx, problem_seed(cfg_index, last["p"], last["step"]), dev)
+        Ap, Bp = gen_pair(n, cplx, problem_seed(cfg_index, last["p"], 0 if args.same_problems else last["step"]), dev)
         wsl = workspace(0, n)
         resid, berr, bortho = check_solution(torch, Ap, Bp, wsl.Z, wsl.w[:m], m)
         del Ap, Bp

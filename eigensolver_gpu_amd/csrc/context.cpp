@@ -2,6 +2,8 @@
 // Replaces module eigsolve_vars (eigsolve_vars.F90:25-61) and nvtx_inters
 // (lib_eigsolve/toolbox.F90:25-99) of the reference.
 #include <dlfcn.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <mutex>
 
@@ -16,6 +18,10 @@ namespace {
 struct CtxHolder {
     std::map<int, Ctx*> m;
     ~CtxHolder() {
+        // The main thread's thread-local destructors run while the process is exiting: the HIP runtime and any attached
+        // profiler are being torn down around us (rocprofv3 aborts on HIP calls made from there) and the driver reclaims
+        // everything anyway -- release only when a WORKER thread ends.  eigsolve_finalize() is the explicit way out.
+        if ((long)syscall(SYS_gettid) == (long)getpid()) return;
         for (auto& kv : m) {
             kv.second->release();
             delete kv.second;

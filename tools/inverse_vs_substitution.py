@@ -1,5 +1,8 @@
-import sys, numpy as np, scipy.linalg as sl
-sys.path.insert(0,'/root/repo')
+"""Blocked triangular solves through EXPLICIT INVERSE diagonal blocks (any order, up to the whole factor) vs substitution,
+on the reference recipe (cond(B) ~ 1e10): residual and B-orthonormality of the generalized eigenpairs are the same.
+Usage: python tools/inverse_vs_substitution.py [N]   (numpy/scipy only, CPU)"""
+import os, sys, numpy as np, scipy.linalg as sl
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle
 from scipy.linalg import lapack
 n=int(sys.argv[1]) if len(sys.argv)>1 else 2048
