@@ -2,8 +2,6 @@
 // Replaces module eigsolve_vars (eigsolve_vars.F90:25-61) and nvtx_inters
 // (lib_eigsolve/toolbox.F90:25-99) of the reference.
 #include <dlfcn.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 
 #include <mutex>
 
@@ -13,19 +11,19 @@
 namespace eig {
 
 namespace {
-// Contexts are owned by the calling thread: when the thread exits its contexts (streams, events, pinned buffers and the
-// grow-only device scratch, ~1 GB at N=4096 complex) are released with it.
+// A context belongs to the thread that uses it.  When that thread ends, its contexts go back to a process-wide pool
+// (no HIP call is made from a thread-local destructor: the runtime -- or an attached profiler, rocprofv3 aborts -- may
+// already be tearing that thread down) and the next thread that needs a context for the same device takes one from the
+// pool, streams, events and cached scratch included.  Threads that come and go therefore neither leak device memory nor
+// pay for hipMalloc / stream creation again.
+std::mutex g_pool_mu;
+std::vector<Ctx*> g_pool;
 struct CtxHolder {
     std::map<int, Ctx*> m;
     ~CtxHolder() {
-        // The main thread's thread-local destructors run while the process is exiting: the HIP runtime and any attached
-        // profiler are being torn down around us (rocprofv3 aborts on HIP calls made from there) and the driver reclaims
-        // everything anyway -- release only when a WORKER thread ends.  eigsolve_finalize() is the explicit way out.
-        if ((long)syscall(SYS_gettid) == (long)getpid()) return;
-        for (auto& kv : m) {
-            kv.second->release();
-            delete kv.second;
-        }
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (auto& kv : m) g_pool.push_back(kv.second);
+        m.clear();
     }
 };
 thread_local CtxHolder t_ctx;
@@ -114,11 +112,48 @@ void Ctx::release() {
     if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);
 }
 
+// tunables: compile-time defaults, overridden by the environment (eigsolve_set_option changes them per context afterwards)
+static void init_options(Ctx& c) {
+    Ctx d;   // defaults
+    c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
+    c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
+    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance;
+    if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_BT_NB")) c.bt_nb = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c.hemv_blocks = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_P_WT")) c.p_wt = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c.hemv_balance = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_GRAPH")) c.use_graph = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c.overlap = atoi(e) & 3;
+    if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c.trsm_base = norm_trsm_base(atoi(e));
+    if (const char* e = getenv("EIGSOLVE_POTRF")) c.potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : (e[0] == '2' ? 2 : 1);
+    if (const char* e = getenv("EIGSOLVE_GST")) c.gst_mode = atoi(e);
+    if (const char* e = getenv("EIGSOLVE_GST_THR")) c.gst_thr = atoi(e);
+    if (c.gst_mode < 0 || c.gst_mode > 3) c.gst_mode = kGstModeDefault;
+    if (c.gst_thr < 256) c.gst_thr = 256;
+    if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c.tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
+    if (c.trd_nb < 1 || c.trd_nb > 64) c.trd_nb = 64;
+    if (c.bt_nb < 1 || c.bt_nb > 128) c.bt_nb = kBtNbDefault;
+    if (c.bt_nb > 64) c.bt_nb = 128;
+    if (c.hemv_blocks > kHemvBlocksMax) c.hemv_blocks = kHemvBlocksMax;
+}
+
 Ctx& ctx() {
     int dev = 0;
     EIG_HIP(hipGetDevice(&dev));
     auto it = t_ctx.m.find(dev);
     if (it != t_ctx.m.end()) return *it->second;
+    {   // a context a finished thread left behind for this device?
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i]->dev == dev) {
+                Ctx* c = g_pool[i];
+                g_pool.erase(g_pool.begin() + i);
+                init_options(*c);          // tunables are per owner: back to the defaults / environment
+                t_ctx.m[dev] = c;
+                return *c;
+            }
+    }
     Ctx* c = new Ctx();
     c->dev = dev;
     // blocking streams, like the reference's cudaStreamCreate (eigsolve_vars.F90:50-52)
@@ -131,24 +166,7 @@ Ctx& ctx() {
     EIG_HIP(hipHostMalloc((void**)&c->h_info, 64, hipHostMallocDefault));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-    if (const char* e = getenv("EIGSOLVE_TRD_NB")) c->trd_nb = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_BT_NB")) c->bt_nb = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c->hemv_blocks = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_P_WT")) c->p_wt = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c->hemv_balance = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_GRAPH")) c->use_graph = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c->overlap = atoi(e) & 3;
-    if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c->trsm_base = norm_trsm_base(atoi(e));
-    if (const char* e = getenv("EIGSOLVE_POTRF")) c->potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : (e[0] == '2' ? 2 : 1);
-    if (const char* e = getenv("EIGSOLVE_GST")) c->gst_mode = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_GST_THR")) c->gst_thr = atoi(e);
-    if (c->gst_mode < 0 || c->gst_mode > 3) c->gst_mode = kGstModeDefault;
-    if (c->gst_thr < 256) c->gst_thr = 256;
-    if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c->tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
-    if (c->trd_nb < 1 || c->trd_nb > 64) c->trd_nb = 64;
-    if (c->bt_nb < 1 || c->bt_nb > 128) c->bt_nb = kBtNbDefault;
-    if (c->bt_nb > 64) c->bt_nb = 128;
-    if (c->hemv_blocks > kHemvBlocksMax) c->hemv_blocks = kHemvBlocksMax;
+    init_options(*c);
     t_ctx.m[dev] = c;
     return *c;
 }
@@ -247,6 +265,18 @@ int eigsolve_init(void) {
 int eigsolve_finalize(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
+    {   // contexts finished threads left behind for this device
+        std::lock_guard<std::mutex> lk(eig::g_pool_mu);
+        for (size_t i = 0; i < eig::g_pool.size();) {
+            if (eig::g_pool[i]->dev == dev) {
+                eig::g_pool[i]->release();
+                delete eig::g_pool[i];
+                eig::g_pool.erase(eig::g_pool.begin() + i);
+            } else {
+                ++i;
+            }
+        }
+    }
     auto it = eig::t_ctx.m.find(dev);
     if (it == eig::t_ctx.m.end()) return 0;
     it->second->release();
