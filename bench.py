@@ -33,6 +33,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The in-flight default (3 problems per GPU) was tuned with the ROCm default of 4 hardware queues per process: with two
+# streams per library context two of the three solves then share one hardware queue.  Measured at C3: 8 or 16 queues
+# (three-way hardware concurrency of dependent-launch chains) 8.3-8.7 problems/s, 1-2 queues 10.0, 4 queues 15.8
+# (profiles/r02_experiments.txt).  Pin the value the numbers were measured with.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TF = 78.6    # MI355X datasheet fp64 matrix
