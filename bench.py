@@ -165,6 +165,7 @@ def main():
 
     def worker_init(t):
         torch.cuda.set_device(local)
+        api.init_eigsolve_gpu()                # the worker's library context (its two streams) is created here, in order
         api.set_option("tridiag", tri)
 
     pool = InflightPool(nthr, init=worker_init)
@@ -399,6 +400,18 @@ def main():
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic": None, "traffic_from_profile": tfp,
                            "algo_bytes_per_launch": per_launch_bytes, "avg_launch_us": per_launch_ms * 1e3}
+        # the same launch sequence for a tridiagonalization of order 8192 (configs[3]): how the fixed per-launch cost
+        # amortises when the operand is larger
+        if n == 4096:
+            n8 = 8192
+            A8 = torch.randn((n8, n8), dtype=torch.float64, device=dev).to(Asw.dtype) if not cplx else \
+                torch.complex(torch.randn((n8, n8), dtype=torch.float64, device=dev), torch.randn((n8, n8), dtype=torch.float64, device=dev))
+            r8 = api.hetrd_mv_sweep(A8, 0, reps=1)
+            ach8 = r8["algo_bytes"] / (r8["ms_total"] * 1e-3) * 1e-9
+            out["roofline"]["sweep_n8192"] = {"launches": r8["launches"], "achieved": ach8, "frac": ach8 / HBM_PEAK_GBS,
+                                              "avg_launch_us": r8["ms_total"] / r8["launches"] * 1e3,
+                                              "algo_bytes_per_launch": r8["algo_bytes"] / r8["launches"]}
+            del A8
         # largest single hemv (n = N-1): what the kernel sustains when the operand is at full size
         x = torch.ones(n, dtype=Asw.dtype, device=dev)
         ms1 = api.hemv_bench(A0, x, reps=20)

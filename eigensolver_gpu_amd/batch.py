@@ -27,17 +27,28 @@ class InflightPool:
         self.nthr = max(1, int(nthr))
         self._in = [queue.Queue() for _ in range(self.nthr)]
         self._out = queue.Queue()
-        self._threads = [threading.Thread(target=self._run, args=(t, init), daemon=True) for t in range(self.nthr)]
-        for th in self._threads:
+        self._threads = []
+        # Workers are started ONE AT A TIME, each finishing its init (where the library context -- two HIP streams -- is
+        # created) before the next starts: HIP deals streams round-robin onto the process' hardware queues, so the order of
+        # creation decides which solves share a queue.  With the ROCm default of 4 queues, sequential creation puts two of
+        # three workers on one queue and the third on another (15.7 problems/s at C3); a racy creation order can spread them
+        # over three queues (11.7, measured: three dependent-launch chains on three hardware queues slow each other down).
+        for t in range(self.nthr):
+            ready = threading.Event()
+            th = threading.Thread(target=self._run, args=(t, init, ready), daemon=True)
             th.start()
+            ready.wait()
+            self._threads.append(th)
 
-    def _run(self, t, init):
+    def _run(self, t, init, ready):
         err = None
         try:
             if init is not None:
                 init(t)
         except BaseException as ex:  # noqa: BLE001 -- reported to the caller of map()
             err = ex
+        finally:
+            ready.set()
         while True:
             job = self._in[t].get()
             if job is None:

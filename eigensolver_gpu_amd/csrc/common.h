@@ -152,6 +152,7 @@ struct Ctx {
                              // 1024-thread block-row kernel, 0: recursive (potrf_rec)
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
+    int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
 
     template <class T> T* scratch(const char* name, size_t count) {

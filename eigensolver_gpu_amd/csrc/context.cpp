@@ -117,7 +117,8 @@ static void init_options(Ctx& c) {
     Ctx d;   // defaults
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
-    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance;
+    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
+    if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c.bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c.hemv_blocks = atoi(e);
@@ -304,6 +305,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
         else if (s == "hemv_balance") c.hemv_balance = value != 0;
         else if (s == "p_wt") c.p_wt = value != 0;
+        else if (s == "real_il_reference") c.real_il_reference = value > 0;
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
         else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : eig::norm_trsm_base(value);

@@ -212,6 +212,9 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     hipStream_t st = c.s1;
     PhaseTimer pt(c);
     const int m = iu - il + 1;
+    // The real reference path copies the eigenvectors from column 1 whatever il is (dsyevd_gpu.F90:108; the complex path
+    // honours il, zheevd_gpu.F90:110).  Default: honour il in both; option "real_il_reference" = 1 reproduces the quirk.
+    if (!Tr<T>::cx && c.real_il_reference) { iu = iu - il + 1; il = 1; }
     phase_range_push(Tr<T>::cx ? "zhetrd" : "dsytrd");   // zheevd_gpu.F90:80
     pt.begin(PH_TRD);
     const T* Vsrc = A;      // where the reflectors live for the back-transformation

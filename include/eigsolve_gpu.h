@@ -39,7 +39,7 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base"};
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance"};
  * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
@@ -54,6 +54,12 @@ int eigsolve_set_host_threads(int nthreads);
  * larger than "gst_thr" (default 1024), two solves below.
  * "trsm_base": order of the inverted diagonal blocks the triangular solves outside potrf stop at, 64 or 256 (default:
  * the 64-block inverses of the factorization merged into 256-block inverses, 4x fewer launches per solve).
+ * "potrf": 1 (default) right-looking Cholesky with block rows of 64 (one block-row kernel + one rank-64 MFMA update per block
+ * row), 2 the same with the 2x2-register-block kernel, 0 the recursive form.  "gst" also accepts 3 = the reference's blocked
+ * loop (zhegst_gpu.F90:51-107) with nb = "trsm_base"; "trsm_base" also accepts 512 / 1024 (inverse blocks merged on MFMA).
+ * "real_il_reference": 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
+ * (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).
+ * "p_wt", "hemv_balance": measured-and-rejected variants of the panel mat-vec kernel (off).
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

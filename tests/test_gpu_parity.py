@@ -1192,3 +1192,22 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     assert d["residual"] < 1e-9
     assert d["c5"]["gathered_eigenvalues_shape"] == [64, 512] and d["c5"]["problems_per_gpu"] == 32
     assert d["c5"]["rerun_bit_identical"] is True
+
+
+def test_real_path_il_quirk_option(env):
+    """dsyevd_gpu.F90:108 copies the eigenvectors from column 1 whatever il is; the default here honours il (like the
+    complex path); option real_il_reference = 1 reproduces the reference's real-path behaviour exactly."""
+    torch, oracle, api = env
+    n, il, iu = 120, 9, 28
+    m = iu - il + 1
+    A = oracle.gen_spd_fast(n, 6100, False)
+    B = oracle.gen_spd_fast(n, 7100, False, shift=float(n))
+    info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), il, iu)
+    assert info == 0 and oracle.residual(A, B, w[il - 1:iu], Z) <= n * EPS
+    try:
+        api.set_option("real_il_reference", 1)
+        info, ws, w2, Zq = run_driver(api, np.triu(A), np.triu(B), il, iu)
+    finally:
+        api.set_option("real_il_reference", 0)
+    assert info == 0 and np.array_equal(w, w2)
+    assert oracle.residual(A, B, w[:m], Zq) <= n * EPS          # columns 1..m hold eigenpairs 1..m
