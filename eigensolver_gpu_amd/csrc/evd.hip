@@ -170,10 +170,12 @@ static void bt_apply(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, 
         Operand<T> Ca = op_plain((const T*)Z, ldz, 1, 1);
         Operand<T> Vb = op_plain(V, lda, 1, 0);
         Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
-        int tiles = (m + 63) / 64;
-        int want = (2 * c.n_cu + tiles - 1) / tiles;        // splits that fill the chip
+        static const int bt_fill = getenv("EIGSOLVE_BT_FILL") ? atoi(getenv("EIGSOLVE_BT_FILL")) : 2;   // workgroups per CU aimed at
+        static const int bt_kmin = getenv("EIGSOLVE_BT_KMIN") ? atoi(getenv("EIGSOLVE_BT_KMIN")) : 128;
+        int tiles = ((m + 63) / 64) * ((ib + 63) / 64);     // 64x64 output tiles of Wk (m x ib)
+        int want = (bt_fill * c.n_cu + tiles - 1) / tiles;  // splits that fill the chip once
         int kchunk = (mi + want - 1) / want;
-        if (kchunk < 128) kchunk = 128;
+        if (kchunk < bt_kmin) kchunk = bt_kmin;
         gemm_splitk<T>(c, st, m, ib, mi, Tr<T>::one(), Ca, Vb, Tr<T>::zero(), Wk, m, kchunk);
         // Wk2 = Wk T^H                                (:197-198)
         Operand<T> Tt = op_plain(Tb, ldt, 0, 1);
