@@ -1025,130 +1025,6 @@ __global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int l
         }
 }
 
-// ------------------------------------------------------------------------------------------------
-// chol_row_cyc_kernel: the same block-row step as chol_row_kernel on a 2-D CYCLIC layout with 4x4 elements per thread:
-// 16 x 16 threads (four waves, one per SIMD), thread (tr, tc) owns rows tr + 16a and columns tc + 16b (a, b = 0..3) of
-// the diagonal block and of its chunk.  Why: the elimination is issue-bound on one CU (PMC on the 2x2 / 1024-thread form:
-// 63 % of the wave cycles waiting at the barrier for the slowest wave, ~90 instructions per thread and step of which 32
-// are the update), so (i) 4x4 register blocks halve the LDS reads per multiply-add, (ii) with cyclic rows the rows
-// already eliminated (<= j) disappear from EVERY thread's work at the same rate -- rows with a < j/16 are skipped
-// statically -- instead of idling whole waves while the last one still carries the full step, (iii) columns left of the
-// diagonal (b < a) are never touched.  Pivot row scaled by its 16 owners (one quarter wave, pivot by v_readlane) and
-// published one step ahead as in chol_row_kernel.
-// ------------------------------------------------------------------------------------------------
-constexpr int CY = 16;            // threads per dimension
-constexpr int CQ = DB / CY;       // 4 elements per thread and dimension
-template <class T>
-__global__ void __launch_bounds__(CY * CY) chol_row_cyc_kernel(int n_total, T* Bm, int ldb, int k0, int* info, unsigned* loaded,
-                                                               unsigned expect) {
-    __shared__ T rowd[2][DB];
-    __shared__ T rowp[2][DB];
-    const int tid = threadIdx.x;
-    const int tr = tid / CY, tc = tid % CY;
-    const int chunk = blockIdx.x;
-    const bool has_p = chunk > 0;
-    const int nb = min(DB, n_total - k0);
-    const int c0 = k0 + chunk * DB;
-    const int pc = min(DB, n_total - c0);
-    T* Dblk = Bm + (size_t)k0 + (size_t)k0 * ldb;
-    T* Pblk = Bm + (size_t)k0 + (size_t)c0 * ldb;
-
-    T u[CQ][CQ], p[CQ][CQ];
-#pragma unroll
-    for (int a = 0; a < CQ; ++a)
-#pragma unroll
-        for (int b = 0; b < CQ; ++b) {
-            const int r = tr + CY * a, cc = tc + CY * b;
-            const bool in = r < nb && cc < nb && r <= cc;
-            const T v = Dblk[(size_t)min(r, nb - 1) + (size_t)min(cc, nb - 1) * ldb];
-            u[a][b] = sel(in, v, sel(r == cc, Tr<T>::one(), Tr<T>::zero()));
-            const T w = Pblk[(size_t)min(r, nb - 1) + (size_t)min(cc, pc - 1) * ldb];
-            p[a][b] = sel(has_p && r < nb && cc < pc, w, Tr<T>::zero());
-        }
-    if (has_p) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // (plain unrolled loops, no lambdas: with the closure form the 4x4 arrays stayed in scratch memory)
-    // owners of row j = 16 l + t (threads tr == t): scale the row, publish it in LDS buffer bufn
-#define EIG_CHOL_PUBLISH(l_, t_, bufn_)                                                                                   \
-    do {                                                                                                                 \
-        const int t2 = (t_);                                                                                             \
-        double dd = read_lane(real_(u[l_][l_]), (t2 & 3) * CY + t2); /* D(j,j): thread (t, t), local (l, l) */           \
-        const int jrow = CY * (l_) + t2;                                                                                 \
-        if (!(dd > 0.0)) {                                                                                               \
-            if (tc == t2 && chunk == 0 && jrow < nb) atomicCAS(info, 0, k0 + jrow + 1);                                  \
-            dd = 1.0;                                                                                                    \
-        }                                                                                                                \
-        const double ipiv = fast_rsqrt(dd);                                                                              \
-        double piv = dd * ipiv;                                                                                          \
-        piv = fma(fma(-piv, piv, dd), 0.5 * ipiv, piv);                                                                  \
-        _Pragma("unroll") for (int b = 0; b < CQ; ++b) {                                                                 \
-            const T sc_ = u[l_][b] * ipiv;                                                                               \
-            u[l_][b] = sel(tc == t2 && b == (l_), Tr<T>::make(piv, 0.0), sc_);                                           \
-            p[l_][b] = p[l_][b] * ipiv;                                                                                  \
-            rowd[bufn_][tc + CY * b] = u[l_][b];                                                                         \
-            rowp[bufn_][tc + CY * b] = p[l_][b];                                                                         \
-        }                                                                                                                \
-    } while (0)
-    // local row a -= conj(U(j, row)) * U(j, my columns); columns left of the diagonal block row (b < a) are never needed
-#define EIG_CHOL_UPD(a_)                                                                                                 \
-    do {                                                                                                                 \
-        _Pragma("unroll") for (int b = 0; b < CQ; ++b) {                                                                 \
-            if (b >= (a_)) fmsc_(u[a_][b], ur[a_], uc[b]);                                                               \
-            if (has_p) fmsc_(p[a_][b], ur[a_], pr[b]);                                                                   \
-        }                                                                                                                \
-    } while (0)
-    if (tr == 0) EIG_CHOL_PUBLISH(0, 0, 0);
-#pragma unroll
-    for (int l = 0; l < CQ; ++l) {
-        for (int t = 0; t < CY; ++t) {
-            const int buf = t & 1;          // row j = 16 l + t lives in buffer j & 1 = t & 1
-            const bool last = (t == CY - 1);
-            __syncthreads();
-            T ur[CQ], uc[CQ], pr[CQ];
-#pragma unroll
-            for (int q = 0; q < CQ; ++q) {
-                ur[q] = rowd[buf][tr + CY * q];
-                uc[q] = rowd[buf][tc + CY * q];
-                pr[q] = rowp[buf][tc + CY * q];
-            }
-            if (tr > t) {                   // local row l is still below the pivot; its owner for t+1 goes first
-                EIG_CHOL_UPD(l);
-                if (tr == t + 1) EIG_CHOL_PUBLISH(l, t + 1, buf ^ 1);
-            }
-#pragma unroll
-            for (int a = l + 1; a < CQ; ++a) {   // rows of the later cyclic rounds: always below the pivot
-                EIG_CHOL_UPD(a);
-                if (a == l + 1 && last && tr == 0) EIG_CHOL_PUBLISH(a, 0, buf ^ 1);   // next pivot row = local row l+1 of tr == 0
-            }
-        }
-    }
-#undef EIG_CHOL_PUBLISH
-#undef EIG_CHOL_UPD
-
-    if (!has_p) {
-        if (tid == 0) {
-            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0)
-                __builtin_amdgcn_s_sleep(4);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < CQ; ++a)
-#pragma unroll
-        for (int b = 0; b < CQ; ++b) {
-            const int r = tr + CY * a, cc = tc + CY * b;
-            if (!has_p) {
-                if (r < nb && cc < nb && r <= cc) Dblk[(size_t)r + (size_t)cc * ldb] = u[a][b];
-            } else {
-                if (r < nb && cc < pc) Pblk[(size_t)r + (size_t)cc * ldb] = p[a][b];
-            }
-        }
-}
-
 // A_kk <- invU^H * Herm(A_kk) * invU for one diagonal block (upper triangle in/out, real diagonal).
 template <class T>
 __global__ void __launch_bounds__(256) hegs2_block_kernel(int nb, T* Ablk, int lda, const T* inv) {
@@ -1472,6 +1348,10 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 // kept for the two-stream option -- spent its time in a chain of 64 one-workgroup factor+invert kernels and ~190 small
 // dependent products: 10.9 ms at C3).  The inverted diagonal blocks the later solves use are formed afterwards, all blocks
 // in parallel.  EIGSOLVE_POTRF=rec / option "potrf" = 0 restores the recursive form.
+// The block-row kernel is latency-bound on its 64 dependent elimination steps (~0.45 us each: reciprocal square root, LDS
+// broadcast, barrier): a 4x4-cyclic 256-thread layout, a scaled look-ahead broadcast and a blocked-by-16 elimination (rank-16
+// updates, 16x fewer barriers per multiply-add) all measured 40-44 us per launch like this one (profiles/r02_experiments.txt;
+// kernels in the git history of round 2).
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
@@ -1485,11 +1365,7 @@ template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb
             const int nb = min(DB, N - k0), rem = N - k0 - nb;
             const int chunks = (rem + DB - 1) / DB;
             expect += (unsigned)chunks;
-            if (c.potrf_mode == 2)
-                hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
-            else
-                hipLaunchKernelGGL((chol_row_cyc_kernel<T>), dim3(1 + chunks), dim3(CY * CY), 0, st, N, B, ldb, k0, c.d_info, loaded,
-                                   expect);
+            hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
             if (rem > 0) {
                 const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
                 Epi e; e.uplo = 1; e.herm_diag = 1;

@@ -148,8 +148,7 @@ struct Ctx {
     };
     std::map<std::string, GraphEntry> graphs;
     int trsm_base = kTrsmBaseDefault;
-    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_cyc_kernel + rank-64 updates), 2: the same with the 2x2 /
-                             // 1024-thread block-row kernel, 0: recursive (potrf_rec)
+    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_kernel + a rank-64 update each), 0: recursive (potrf_rec)
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108

@@ -127,7 +127,7 @@ static void init_options(Ctx& c) {
     if (const char* e = getenv("EIGSOLVE_GRAPH")) c.use_graph = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_OVERLAP")) c.overlap = atoi(e) & 3;
     if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c.trsm_base = norm_trsm_base(atoi(e));
-    if (const char* e = getenv("EIGSOLVE_POTRF")) c.potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : (e[0] == '2' ? 2 : 1);
+    if (const char* e = getenv("EIGSOLVE_POTRF")) c.potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : 1;
     if (const char* e = getenv("EIGSOLVE_GST")) c.gst_mode = atoi(e);
     if (const char* e = getenv("EIGSOLVE_GST_THR")) c.gst_thr = atoi(e);
     if (c.gst_mode < 0 || c.gst_mode > 3) c.gst_mode = kGstModeDefault;
@@ -309,7 +309,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
         else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : eig::norm_trsm_base(value);
-        else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : (value == 2 ? 2 : 1);
+        else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
         else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? eig::kGstModeDefault : value;
         else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);

@@ -55,7 +55,7 @@ int eigsolve_set_host_threads(int nthreads);
  * "trsm_base": order of the inverted diagonal blocks the triangular solves outside potrf stop at, 64 or 256 (default:
  * the 64-block inverses of the factorization merged into 256-block inverses, 4x fewer launches per solve).
  * "potrf": 1 (default) right-looking Cholesky with block rows of 64 (one block-row kernel + one rank-64 MFMA update per block
- * row), 2 the same with the 2x2-register-block kernel, 0 the recursive form.  "gst" also accepts 3 = the reference's blocked
+ * row), 0 the recursive form.  "gst" also accepts 3 = the reference's blocked
  * loop (zhegst_gpu.F90:51-107) with nb = "trsm_base"; "trsm_base" also accepts 512 / 1024 (inverse blocks merged on MFMA).
  * "real_il_reference": 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
  * (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).

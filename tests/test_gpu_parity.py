@@ -133,10 +133,9 @@ def test_her2k_vs_numpy(env, cplx, n, k):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n", [1, 2, 31, 64, 65, 129, 300])
-@pytest.mark.parametrize("mode", [1, 2, 0])
+@pytest.mark.parametrize("mode", [1, 0])
 def test_potrf_and_trsm_vs_oracle(env, cplx, n, mode):
-    """mode 1: right-looking block rows, cyclic 4x4 block-row kernel (default); 2: the same with the 2x2 / 1024-thread
-    kernel; 0: the recursive form."""
+    """mode 1: right-looking block rows (chol_row_kernel, default); mode 0: the recursive form."""
     torch, oracle, api = env
     B = oracle.gen_spd(n, 2000 + n, cplx, shift=float(n))
     Bin = np.triu(B).copy()
