@@ -109,6 +109,28 @@ def test_gemm_vs_numpy(env, cplx, ta, tb, dims):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,k", [(2600, 64), (2111, 50), (3000, 128)])
+def test_her2k_many_tiles_vs_numpy(env, cplx, n, k):
+    """Short-K updates over more tiles than resident workgroups (the trailing updates of the tridiagonalization and of the
+    Cholesky factorization at full size): values against numpy, ragged edges, strict lower triangle untouched."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n + k)
+    V, W = rnd(rng, cplx, n, k), rnd(rng, cplx, n, k)
+    C = rnd(rng, cplx, n, n)
+    C = C + C.conj().T
+    Cd = api.to_device(C)
+    api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+    got = api.to_host(Cd)
+    ref = C - V @ W.conj().T - W @ V.conj().T
+    iu = np.triu_indices(n)
+    assert np.abs(got[iu] - ref[iu]).max() <= 50 * k * EPS * np.abs(ref).max()
+    il = np.tril_indices(n, -1)
+    assert np.array_equal(got[il], C[il])
+    if cplx:
+        assert np.all(got.diagonal().imag == 0)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n,k", [(1, 1), (64, 64), (100, 32), (333, 64), (130, 7)])
 def test_her2k_vs_numpy(env, cplx, n, k):
     """trailing update zhetrd_gpu.F90:67: upper only, real diagonal, lower untouched."""
