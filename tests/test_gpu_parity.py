@@ -1213,6 +1213,16 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     assert d["residual"] < 1e-9
     assert d["c5"]["gathered_eigenvalues_shape"] == [64, 512] and d["c5"]["problems_per_gpu"] == 32
     assert d["c5"]["rerun_bit_identical"] is True
+    # the C5 workload as the timed region (strong scaling: 64 problems over the ranks), at a small order
+    cmd2 = cmd[:cmd.index(os.path.join(root, "bench.py")) + 1] + [
+        "--gpus", "2", "--workload", "c5", "--steps", "1", "--warmup", "1", "--order", "256", "--share-gpu", "--backend", "gloo",
+        "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag", "--inflight", "2"]
+    cmd2[cmd2.index("29531")] = "29532"
+    out = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["problems_per_step_total"] == 64 and d["config"]["problems_per_gpu_per_step"] == 32
+    assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
 
 
 def test_real_path_il_quirk_option(env):
