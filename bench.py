@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--batch", type=int, default=3, help="(c3) independent problems per GPU per step")
     ap.add_argument("--inflight", type=int, default=3, help="problems in flight per GPU (persistent host threads / contexts); "
                     "measured on MI355X at C3: 2 -> 14.4, 3 -> 15.7, 4 -> 12.8 problems/s")
+    ap.add_argument("--fuse", type=int, default=1, help="problems per solver call (eigsolve_?hegvdx_batch: tridiagonalizations of "
+                    "the group in lockstep); 1 = the reference's one-problem-per-call driver")
     ap.add_argument("--isolated-reps", type=int, default=3, help="isolated single solves timed before the batch (median/min reported)")
     ap.add_argument("--tridiag", choices=["device", "host"], default="device",
                     help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
@@ -170,11 +172,13 @@ def main():
 
     pool = InflightPool(nthr, init=worker_init)
 
-    def workspace(t, nn):
-        key = (t, nn)
+    def workspace(t, nn, k=0):
+        key = (t, nn, k)
         if key not in wss:
             wss[key] = api.Workspace(nn, cplx)
         return wss[key]
+
+    fuse = max(1, args.fuse)
 
     # ---- the batch of one step: total problems and this rank's share ----------------------------------------------
     cfg_index = 4 if c5 else 2
@@ -185,12 +189,26 @@ def main():
         for p in mine:
             staged[(s, p)] = gen_pair(n, cplx, problem_seed(cfg_index, p, 0 if args.same_problems else s), dev)
     for t in range(nthr):
-        workspace(t, n)
+        for k in range(fuse):
+            workspace(t, n, k)
     torch.cuda.synchronize()
     phases = []
     last = {}
 
     def make_solver(step):
+        def solve_group(group, t):
+            pairs = [staged[(step, p)] for p in group]
+            wl = [workspace(t, n, k) for k in range(len(group))]
+            infos = api.hegvdx_batch(pairs, 1, m, wl)
+            if any(infos):
+                raise RuntimeError("hegvdx_batch infos=%s (problems %s, step %d)" % (infos, group, step))
+            if t == 0:
+                last["p"], last["step"] = group[0], step
+            return [w_.w[:m].clone() for w_ in wl]
+
+        if fuse > 1:
+            return solve_group
+
         def solve(p, t):
             A, B = staged[(step, p)]
             ws = workspace(t, n)
@@ -236,7 +254,7 @@ def main():
 
     # ---- warm-up steps, then EXACTLY K timed steps between barriers ------------------------------------------------
     for s in range(W):
-        run_sharded_batch(n_total, rank, world, make_solver(s), pool)
+        run_sharded_batch(n_total, rank, world, make_solver(s), pool, fuse)
     phases.clear()
     barrier()
     step_ms = []
@@ -244,7 +262,7 @@ def main():
     results = None
     for s in range(W, W + K):
         ts = time.perf_counter()
-        results = run_sharded_batch(n_total, rank, world, make_solver(s), pool)
+        results = run_sharded_batch(n_total, rank, world, make_solver(s), pool, fuse)
         if args.log_steps:
             torch.cuda.synchronize()
             step_ms.append((time.perf_counter() - ts) * 1e3)
@@ -302,7 +320,7 @@ def main():
             "dtype": "c128" if cplx else "f64",
             "data": "synthetic (reference recipe A=T*T^H, B=T'*T'^H, uniform[0,1) entries, seeded; every problem distinct)",
             "config": {"workload": workload, "lda": n, "il": 1, "iu": m, "problems_per_step_total": n_total,
-                       "problems_per_gpu_per_step": len(mine), "inflight_per_gpu": nthr,
+                       "problems_per_gpu_per_step": len(mine), "inflight_per_gpu": nthr, "problems_per_solver_call": fuse,
                        "parallelism": "batch-over-gpus x%d" % world},
             "ms_per_solve": sorted(iso)[len(iso) // 2],
             "ms_per_solve_min": min(iso),
@@ -340,6 +358,13 @@ def main():
                 raise RuntimeError("c5 hegvdx info=%d (problem %d)" % (info, p))
             return ws.w[:m5].clone()
 
+        def solve5_group(group, t):
+            wl = [workspace(t, n5, k) for k in range(len(group))]
+            infos = api.hegvdx_batch([st5[p] for p in group], 1, m5, wl)
+            if any(infos):
+                raise RuntimeError("c5 hegvdx_batch infos=%s (problems %s)" % (infos, group))
+            return [w_.w[:m5].clone() for w_ in wl]
+
         def warm5(t_, t):
             A, B = warm[t]
             api.hegvdx(A, B, 1, m5, workspace(t, n5))
@@ -348,7 +373,7 @@ def main():
         pool.map(warm5, list(range(nthr)))     # sizes every context's scratch for N=2048 outside the timed pass
         barrier()
         t5 = time.perf_counter()
-        res5 = run_sharded_batch(C5_PROBLEMS, rank, world, solve5, pool)
+        res5 = run_sharded_batch(C5_PROBLEMS, rank, world, solve5_group if fuse > 1 else solve5, pool, fuse)
         barrier()
         el5 = time.perf_counter() - t5
         r5 = [el5 * 1e3]

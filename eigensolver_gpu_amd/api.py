@@ -38,6 +38,7 @@ EXPORTS = [
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
     "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
     "eigsolve_dstedc_device", "eigsolve_zlarft", "eigsolve_dlarft", "eigsolve_zunmtr", "eigsolve_dormtr",
+    "eigsolve_zhegvdx_batch", "eigsolve_dsygvdx_batch",
 ]
 
 
@@ -203,6 +204,36 @@ def hegvdx(A_d, B_d, il, iu, ws=None, skip_host_copy=False):
         info = dsygvdx_gpu(N, A_d, N, B_d, N, ws.Z, N, il, iu, ws.w, ws.work, ws.lwork, ws.work_h, ws.lwork_h, ws.iwork_h,
                            ws.liwork_h, ws.Z_h, N, ws.w_h, skip_host_copy)
     return info, ws
+
+
+def hegvdx_batch(pairs, il, iu, wss, skip_host_copy=False):
+    """nprob problems of ONE order and type in one call (eigsolve_zhegvdx_batch / eigsolve_dsygvdx_batch): the
+    tridiagonalizations run in lockstep, per-problem results are bit-identical to `hegvdx`.  pairs = [(A_d, B_d), ...]
+    (overwritten like in the reference), wss = one Workspace per problem.  Returns the list of per-problem info values."""
+    import torch
+    _sync()
+    nprob = len(pairs)
+    assert nprob >= 1 and len(wss) >= nprob
+    N = pairs[0][0].shape[0]
+    cx = pairs[0][0].dtype == torch.complex128
+
+    def arr(ts):
+        return (c_void_p * nprob)(*[t.data_ptr() for t in ts])
+
+    A, B = arr([p[0] for p in pairs]), arr([p[1] for p in pairs])
+    Z, w, work = arr([ws.Z for ws in wss[:nprob]]), arr([ws.w for ws in wss[:nprob]]), arr([ws.work for ws in wss[:nprob]])
+    Zh, wh = arr([ws.Z_h for ws in wss[:nprob]]), arr([ws.w_h for ws in wss[:nprob]])
+    info = (c_int * nprob)()
+    ws0 = wss[0]
+    if cx:
+        rwork = arr([ws.rwork for ws in wss[:nprob]])
+        lib().eigsolve_zhegvdx_batch(c_int(nprob), c_int(N), A, c_int(N), B, c_int(N), Z, c_int(N), c_int(il), c_int(iu), w, work,
+                                     c_int(ws0.lwork), rwork, c_int(ws0.lrwork), Zh, c_int(N), wh, info,
+                                     c_int(1 if skip_host_copy else 0))
+    else:
+        lib().eigsolve_dsygvdx_batch(c_int(nprob), c_int(N), A, c_int(N), B, c_int(N), Z, c_int(N), c_int(il), c_int(iu), w, work,
+                                     c_int(ws0.lwork), Zh, c_int(N), wh, info, c_int(1 if skip_host_copy else 0))
+    return [info[q] for q in range(nprob)]
 
 
 def diaghg(H_d, S_d, m, ws=None):

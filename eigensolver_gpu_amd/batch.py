@@ -94,13 +94,19 @@ class InflightPool:
         self.close()
 
 
-def run_sharded_batch(n_problems, rank, world, solve, pool):
+def run_sharded_batch(n_problems, rank, world, solve, pool, fuse=1):
     """Solves this rank's share of a batch of independent problems: p -> rank (p mod world), the rank's problems
-    spread over the pool's in-flight workers.  `solve(p, t)` returns the eigenvalues of problem p (a 1-D tensor)
-    computed by worker t.  No communication.  Returns {problem id: eigenvalues}."""
+    spread over the pool's in-flight workers.  fuse = 1: `solve(p, t)` returns the eigenvalues of problem p (a 1-D tensor)
+    computed by worker t.  fuse = F > 1: the rank's problems are handed out in groups of F (same order, one
+    `eigsolve_?hegvdx_batch` call: tridiagonalizations in lockstep) and `solve(group, t)` returns one tensor per problem
+    of the group.  No communication.  Returns {problem id: eigenvalues}."""
     mine = shard_problems(n_problems, rank, world)
-    vals = pool.map(solve, mine)
-    return dict(zip(mine, vals))
+    if fuse <= 1:
+        vals = pool.map(solve, mine)
+        return dict(zip(mine, vals))
+    groups = [mine[i:i + fuse] for i in range(0, len(mine), fuse)]
+    outs = pool.map(solve, groups)
+    return {p: v for g, vs in zip(groups, outs) for p, v in zip(g, vs)}
 
 
 def gather_eigenvalues(local, n_problems, m):

@@ -420,6 +420,83 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     return 0;
 }
 
+// ---- batch of same-order problems: lockstep tridiagonalization ----------------------------------------------
+// QE k-point style batches (BASELINE.json configs[4]) are many problems of ONE order.  The per-column kernels of the
+// tridiagonalization -- 2/3 of a solve -- are latency-bound for most of the reduction, so nprob problems share every
+// per-column launch (hetrd_upper_batch); the BLAS-3 phases and the tridiagonal eigensolver run problem after problem on the
+// same stream with the context's scratch.  Per-problem results are bit-identical to the single-problem driver's.
+// Device tridiagonal solver only (the host dstedc path solves the problems one by one through hegvdx_core).
+template <class T>
+static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* const* B, int ldb, T* const* Z, int ldz, int il, int iu,
+                             double* const* w_d, double* const* e_d, T* const* tau_d, T* const* W_d, double* const* w_h,
+                             T* const* Z_h, int ldz_h, int skip_host_copy, int* infos, const char* name) {
+    hipStream_t st = c.s1;
+    clear_phases(c);
+    const double t_all = now_ms();
+    const int m = iu - il + 1;
+    int* h_inf = reinterpret_cast<int*>(c.host_scratch_bytes("batch_info", sizeof(int) * (size_t)nprob));
+    {
+        PhaseRange r("batch: potrf + hegst");
+        for (int q = 0; q < nprob; ++q) {
+            potrf_upper<T>(c, st, N, B[q], ldb);
+            EIG_HIP(hipMemcpyAsync(&h_inf[q], c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+            hegst_upper<T>(c, st, N, A[q], lda, B[q], ldb);     // (meaningless if B[q] was not positive definite: checked below)
+        }
+    }
+    {
+        PhaseRange r(Tr<T>::cx ? "batch: zhetrd lockstep" : "batch: dsytrd lockstep");
+        hetrd_upper_batch<T>(c, st, N, nprob, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
+    }
+    EIG_HIP(hipStreamSynchronize(st));
+    int bad = 0;
+    for (int q = 0; q < nprob; ++q) {
+        infos[q] = 0;
+        if (h_inf[q] != 0) {
+            printf(" %s error: potrf failed! (B is not positive definite, pivot %d; batch problem %d)\n", name, h_inf[q], q);
+            infos[q] = -1;
+            bad = 1;
+        }
+    }
+    for (int q = 0; q < nprob; ++q) {
+        if (infos[q] != 0) continue;
+        double* Qd = nullptr;
+        int ldq_d = 0;
+        {
+            PhaseRange r(Tr<T>::cx ? "zstedc" : "dstedc");
+            if (stedc_device(c, st, N, w_d[q], e_d[q], w_d[q], &Qd, &ldq_d, il, iu) != 0) {
+                printf(" eigsolve error: device tridiagonal eigensolver failed! (batch problem %d)\n", q);
+                infos[q] = -1;
+                bad = 1;
+                continue;
+            }
+        }
+        size_t tot = (size_t)N * m;
+        hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m,
+                           (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Z[q], ldz);
+        EIG_HIP(hipMemcpyAsync(w_h[q], w_d[q], sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        {
+            PhaseRange r(Tr<T>::cx ? "zunmtr" : "dormtr");
+            bt_build_T<T>(c, st, N, A[q], lda, tau_d[q], c.bt_nb);
+            bt_apply<T>(c, st, N, m, A[q], lda, Z[q], ldz, c.bt_nb);
+        }
+        // the inverse diagonal blocks in the context's scratch are those of the LAST factorization: rebuild problem q's
+        build_invU<T>(c, st, N, (const T*)B[q], ldb);
+        build_inv_blocks<T>(c, st, N, (const T*)B[q], ldb);
+        trsm_LUN<T>(c, st, N, m, B[q], ldb, 0, Z[q], ldz, c.trsm_base);
+        if (!skip_host_copy) {
+            hipError_t e = hipMemcpy2DAsync(Z_h[q], sizeof(T) * ldz_h, Z[q], sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
+            if (e != hipSuccess) {
+                printf(" %s error: hipMemcpy2D failed!\n", name);
+                infos[q] = -1;
+                bad = 1;
+            }
+        }
+    }
+    EIG_HIP(hipStreamSynchronize(st));
+    c.phase_ms[PH_TOTAL] = now_ms() - t_all;
+    return bad ? -1 : 0;
+}
+
 template <class F> static int guarded(int* info, F&& f) {
     int r;
     try {
@@ -506,6 +583,46 @@ int eigsolve_dsygvdx(int N, double* A_d, int lda, double* B_d, int ldb, double* 
         long lswork = (long)lwork_h - 2 * n - n * n;
         return hegvdx_core<double>(c, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e_d, tau, W, w_h, e_h, Q_h, N, swork, lswork,
                                    iwork_h, liwork_h, Z_h, ldz_h, skip_host_copy, "dsygvdx_gpu");
+    });
+}
+
+int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* const* B_d, int ldb, void* const* Z_d, int ldz, int il,
+                           int iu, double* const* w_d, void* const* work_d, int lwork, double* const* rwork_d, int lrwork,
+                           void* const* Z_h, int ldz_h, double* const* w_h, int* info, int skip_host_copy) {
+    int rc = guarded(nullptr, [&]() -> int {
+        const long n = N;
+        if (nprob < 1 || nprob > 64) { printf(" zhegvdx_gpu batch error: nprob must be in 1..64\n"); return -1; }
+        if (lwork < 2 * 64 * 64 + 65 * n) { printf(" zhegvdx_gpu error: lwork must be at least 2*64*64 + 65*N\n"); return -1; }
+        if (lrwork < n) { printf(" zhegvdx_gpu error: lrwork must be at least N\n"); return -1; }
+        if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" zhegvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        Ctx& c = ctx();
+        if (!c.tridiag_device) { printf(" zhegvdx_gpu batch error: the batch driver needs the device tridiagonal solver (tridiag = 1)\n"); return -1; }
+        std::vector<cplx*> A(nprob), B(nprob), Z(nprob), tau(nprob), W(nprob), Zh(nprob);
+        std::vector<double*> e(nprob);
+        for (int q = 0; q < nprob; ++q) {
+            A[q] = (cplx*)A_d[q]; B[q] = (cplx*)B_d[q]; Z[q] = (cplx*)Z_d[q]; Zh[q] = Z_h ? (cplx*)Z_h[q] : nullptr;
+            tau[q] = (cplx*)work_d[q]; W[q] = (cplx*)work_d[q] + n; e[q] = rwork_d[q];       // carve-up of zheevd_gpu.F90:68-75
+        }
+        return hegvdx_batch_core<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
+                                       W.data(), w_h, Zh.data(), ldz_h, skip_host_copy, info, "zhegvdx_gpu");
+    });
+    return rc;
+}
+
+int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double* const* B_d, int ldb, double* const* Z_d, int ldz, int il,
+                           int iu, double* const* w_d, double* const* work_d, int lwork, double* const* Z_h, int ldz_h,
+                           double* const* w_h, int* info, int skip_host_copy) {
+    return guarded(nullptr, [&]() -> int {
+        const long n = N;
+        if (nprob < 1 || nprob > 64) { printf(" dsygvdx_gpu batch error: nprob must be in 1..64\n"); return -1; }
+        if (lwork < 2 * 64 * 64 + 66 * n) { printf(" dsygvdx_gpu error: lwork must be at least 2*64*64 + 66*N\n"); return -1; }
+        if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" dsygvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        Ctx& c = ctx();
+        if (!c.tridiag_device) { printf(" dsygvdx_gpu batch error: the batch driver needs the device tridiagonal solver (tridiag = 1)\n"); return -1; }
+        std::vector<double*> e(nprob), tau(nprob), W(nprob);
+        for (int q = 0; q < nprob; ++q) { e[q] = work_d[q]; tau[q] = work_d[q] + n; W[q] = work_d[q] + 2 * n; }   // dsyevd_gpu.F90:68-74
+        return hegvdx_batch_core<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h, Z_h,
+                                         ldz_h, skip_host_copy, info, "dsygvdx_gpu");
     });
 }
 

@@ -9,6 +9,12 @@ namespace eig {
 template <class T>
 void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb);
 
+// nprob problems of the same order in lockstep: every per-column launch of the panels carries all of them (arrays of
+// per-problem pointers; workspaces as for hetrd_upper).  Results per problem are bit-identical to hetrd_upper's.
+template <class T>
+void hetrd_upper_batch(Ctx& c, hipStream_t st, int N, int nprob, T* const* A, int lda, double* const* d, double* const* e,
+                       T* const* tau, T* const* W, int nb);
+
 // y = A x, A Hermitian upper (zhemv_gpu.F90:33-193).  gather=false leaves only the tile
 // partials in scratch (used to time the HBM-bound kernel alone).
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather);

@@ -79,6 +79,14 @@ __device__ __forceinline__ void store_partial(double* p, double v, int wt) {
     else *p = v;
 }
 
+// A launch serves NB independent problems of the same order in lockstep (blockIdx.y = problem): the per-column kernels of
+// a tridiagonalization are latency-bound for most of the reduction (4.3-4.8 us per mat-vec launch up to
+// n = 1280 whatever the work), so two problems per launch cost little more than one.  NB = 1 is the single-problem path.
+constexpr int MAXB = 4;
+template <class T, int NB> struct PanelBatch {
+    PanelArgs<T> p[NB];
+};
+
 // larfg scalars with the reference's scaling (zhetrd_gpu.F90:275-311: scale by max(|ar|,|ai|,xnorm), no
 // safe-minimum loop).  Degenerate case follows LAPACK (tau=0, beta=ar).  This sits on the critical path of
 // every column (all lanes of a wave evaluate it redundantly), so the three quotients are multiplications by
@@ -129,8 +137,9 @@ constexpr int SC = 2;    // v^H A v partials per lane without the tail loop (512
 // FIN / UPD are compile-time, and RU / RP (panel columns / hemv stripes per lane, rounded up by the host) size
 // the unconditional load groups: every load is issued, in a fixed order, so the compiler can wait for exactly
 // the values it needs (s_waitcnt vmcnt(k) with the later loads still in flight) instead of for everything.
-template <class T, bool FIN, bool UPD, int RU, int RP>
-__global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a) {
+template <class T, bool FIN, bool UPD, int RU, int RP, int NB>
+__global__ void __launch_bounds__(256) panel_row_kernel(PanelBatch<T, NB> ab) {
+    const PanelArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
     constexpr bool do_finish = FIN, do_update = UPD;
     const int i = a.i, c = i + 1;
     const int npo = do_finish ? a.np - 1 - c : 0;  // columns older than c inside the panel
@@ -274,11 +283,11 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelArgs<T> a) {
 }
 
 // host-side choice of the load-group sizes
-template <class T, bool FIN, bool UPD>
-static void launch_row(hipStream_t st, int grid, const PanelArgs<T>& a, int npo, int ntc) {
+template <class T, bool FIN, bool UPD, int NB>
+static void launch_row(hipStream_t st, int grid, int nprob, const PanelBatch<T, NB>& a, int npo, int ntc) {
     const int ru = npo <= 16 ? 1 : (npo <= 32 ? 2 : (npo <= 48 ? 3 : 4));
     const int rp = ntc <= 16 ? 1 : (ntc <= 32 ? 2 : (ntc <= 64 ? 4 : 8));
-#define EIG_ROW(RU_, RP_) hipLaunchKernelGGL((panel_row_kernel<T, FIN, UPD, RU_, RP_>), dim3(grid), dim3(256), 0, st, a)
+#define EIG_ROW(RU_, RP_) hipLaunchKernelGGL((panel_row_kernel<T, FIN, UPD, RU_, RP_, NB>), dim3(grid, nprob), dim3(256), 0, st, a)
 #define EIG_ROW_RP(RU_) do { if (rp == 1) EIG_ROW(RU_, 1); else if (rp == 2) EIG_ROW(RU_, 2); else if (rp == 4) EIG_ROW(RU_, 4); else EIG_ROW(RU_, 8); } while (0)
     if constexpr (!FIN) { EIG_ROW(1, 1); }
     else if constexpr (!UPD) { EIG_ROW_RP(4); }   // once per panel: only the stripe count is specialised
@@ -314,8 +323,9 @@ __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
     I = t - J * (J + 1) / 2;
 }
 
-template <class T>
-__global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelArgs<T> a, int plain, int gg) {
+template <class T, int NB>
+__global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, int plain, int gg) {
+    const PanelArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
     const int i = a.i, n = i;  // v has n entries (rows 0..i-1), v(n-1) = 1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if EIG_TRD_TIMING
@@ -655,39 +665,55 @@ template <class T> struct TrdScratch {
     int ldp;
 };
 
-template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N) {
+template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N, int prob = 0) {
     TrdScratch<T> s;
     int nt = (N + HT - 1) / HT;
     s.ldp = nt * HT;
-    s.xbuf = c.scratch<T>("trd_xbuf", (size_t)nt * HT + 64);
-    s.P = c.scratch<T>("trd_P", (size_t)nt * s.ldp);
-    s.S = c.scratch<T>("trd_S", 8192);
+    char nm[6][24];
+    const char* base[6] = {"trd_xbuf", "trd_P", "trd_S", "trd_Zp", "trd_NP", "trd_alpha"};
+    for (int q = 0; q < 6; ++q) {
+        if (prob == 0) snprintf(nm[q], sizeof nm[q], "%s", base[q]);     // (the single-problem slot names of round 1)
+        else snprintf(nm[q], sizeof nm[q], "%s#%d", base[q], prob);
+    }
+    s.xbuf = c.scratch<T>(nm[0], (size_t)nt * HT + 64);
+    s.P = c.scratch<T>(nm[1], (size_t)nt * s.ldp);
+    s.S = c.scratch<T>(nm[2], 8192);
     int nchunk = (N + CH - 1) / CH;
-    s.Zp = c.scratch<T>("trd_Zp", (size_t)(nchunk + 1) * 2 * NBMAX);
-    s.NP = c.scratch<double>("trd_NP", (size_t)(N / RR + 1) * NPW + 64);
-    s.alphaSlot = c.scratch<T>("trd_alpha", 8);
+    s.Zp = c.scratch<T>(nm[3], (size_t)(nchunk + 1) * 2 * NBMAX);
+    s.NP = c.scratch<double>(nm[4], (size_t)(N / RR + 1) * NPW + 64);
+    s.alphaSlot = c.scratch<T>(nm[5], 8);
     return s;
 }
 
-template <class T>
-static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np, int nb, T* A, int lda, double* e, T* tau,
-                        T* W, int ldw, bool mv_only = false, long* nlaunch = nullptr, double* algo_bytes = nullptr) {
-    PanelArgs<T> a;
-    a.A = A; a.lda = lda; a.W = W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = e; a.tau = tau;
-    a.xbuf = sc.xbuf; a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp; a.NP = sc.NP; a.alphaSlot = sc.alphaSlot;
-    a.wt = c.p_wt;
+// one problem of a lockstep batch: its matrix, outputs, panel workspace and private scratch
+template <class T> struct TrdProb {
+    T* A; double* d; double* e; T* tau; T* W;
+    TrdScratch<T> sc;
+};
+
+template <class T, int NB>
+static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr, int np, int nb, int lda, int ldw,
+                        bool mv_only = false, long* nlaunch = nullptr, double* algo_bytes = nullptr) {
+    PanelBatch<T, NB> ab;
+    for (int q = 0; q < NB; ++q) {
+        const TrdProb<T>& P = pr[q < nprob ? q : 0];
+        PanelArgs<T>& a = ab.p[q];
+        a.A = P.A; a.lda = lda; a.W = P.W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = P.e; a.tau = P.tau;
+        a.xbuf = P.sc.xbuf; a.P = P.sc.P; a.ldp = P.sc.ldp; a.S = P.sc.S; a.Zp = P.sc.Zp; a.NP = P.sc.NP; a.alphaSlot = P.sc.alphaSlot;
+        a.wt = c.p_wt;
+    }
+    auto set_all = [&](auto f) { for (int q = 0; q < NB; ++q) f(ab.p[q]); };
     int gh_prev = 0, nchunk_prev = 0;
     for (int i = np - 1; i >= np - nb - 1; --i) {
         const bool last = (i == np - nb - 1);  // finish-only pass for the panel's leftmost column
         const int do_finish = (i < np - 1), do_update = !last;
-        a.i = i;
-        a.gh = gh_prev; a.nchunk = nchunk_prev;
+        set_all([&](PanelArgs<T>& a) { a.i = i; a.gh = gh_prev; a.nchunk = nchunk_prev; });
         int gA = (i + 1 + RR - 1) / RR;
         if (!mv_only) {
-            const int c = i + 1, npo = do_finish ? np - 1 - c : 0, ntc = (c + HT - 1) / HT;
-            if (!do_finish) launch_row<T, false, true>(st, gA, a, npo, ntc);
-            else if (do_update) launch_row<T, true, true>(st, gA, a, npo, ntc);
-            else launch_row<T, true, false>(st, gA, a, npo, ntc);
+            const int cc = i + 1, npo = do_finish ? np - 1 - cc : 0, ntc = (cc + HT - 1) / HT;
+            if (!do_finish) launch_row<T, false, true, NB>(st, gA, nprob, ab, npo, ntc);
+            else if (do_update) launch_row<T, true, true, NB>(st, gA, nprob, ab, npo, ntc);
+            else launch_row<T, true, false, NB>(st, gA, nprob, ab, npo, ntc);
         }
         if (last) break;
         // mat-vec for column i (v has i entries)
@@ -696,8 +722,8 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
         int nchunk = (n + CH - 1) / CH;
         int npo = np - 1 - i;
         int gg = (2 * npo * nchunk + 3) / 4;
-        a.nblkA = gA * NPW; a.gh = gh; a.nchunk = nchunk;
-        hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(gh + gg), dim3(MVT), 0, st, a, 0, gg);
+        set_all([&](PanelArgs<T>& a) { a.nblkA = gA * NPW; a.gh = gh; a.nchunk = nchunk; });
+        hipLaunchKernelGGL((panel_mv_kernel<T, NB>), dim3(gh + gg, nprob), dim3(MVT), 0, st, ab, 0, gg);
         if (nlaunch) ++*nlaunch;
         if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
         gh_prev = gh; nchunk_prev = nchunk;
@@ -705,30 +731,59 @@ static void latrd_panel(Ctx& c, hipStream_t st, const TrdScratch<T>& sc, int np,
     EIG_HIP(hipGetLastError());
 }
 
-template <class T>
-void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb) {
+// nprob problems of order N reduced in lockstep: every per-column launch carries all of them (blockIdx.y); the trailing
+// rank-2nb updates and the final 32x32 blocks are launched per problem.  nprob = 1 is the plain zhetrd_gpu path.
+template <class T, int NB>
+static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdProb<T>* pr, int lda, int nb) {
     if (N <= 0) return;
     if (nb <= 0 || nb > NBMAX) nb = NBMAX;
     const int nx = TD;
-    TrdScratch<T> sc = trd_scratch<T>(c, N);
     const int ldw = N;
     int np = N;
+    auto trailing = [&](int npn, int nbn) {
+        for (int q = 0; q < nprob; ++q)
+            her2k_un<T>(c, st, npn - nbn, nbn, pr[q].A + (size_t)(npn - nbn) * lda, lda, pr[q].W, ldw, pr[q].A, lda);
+    };
     while (np - nb >= nx) {  // zhetrd_gpu.F90:60-71
-        latrd_panel(c, st, sc, np, nb, A, lda, e, tau, W, ldw);
-        her2k_un<T>(c, st, np - nb, nb, A + (size_t)(np - nb) * lda, lda, W, ldw, A, lda);
+        latrd_panel<T, NB>(c, st, nprob, pr, np, nb, lda, ldw);
+        trailing(np, nb);
         np -= nb;
     }
     int nbr = np - nx;  // remainder panel, :73-83
     if (nbr > 0) {
-        latrd_panel(c, st, sc, np, nbr, A, lda, e, tau, W, ldw);
-        her2k_un<T>(c, st, np - nbr, nbr, A + (size_t)(np - nbr) * lda, lda, W, ldw, A, lda);
+        latrd_panel<T, NB>(c, st, nprob, pr, np, nbr, lda, ldw);
+        trailing(np, nbr);
         np = nx;
     }
     int n0 = N < nx ? N : nx;
-    hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, A, lda, d, e, tau);
-    if (N > n0)
-        hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - n0 + 255) / 256), dim3(256), 0, st, n0, N, (const T*)A, lda, d);
+    for (int q = 0; q < nprob; ++q) {
+        hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);
+        if (N > n0)
+            hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - n0 + 255) / 256), dim3(256), 0, st, n0, N, (const T*)pr[q].A, lda,
+                               pr[q].d);
+    }
     EIG_HIP(hipGetLastError());
+}
+
+template <class T>
+void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb) {
+    if (N <= 0) return;
+    TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N)};
+    hetrd_lockstep<T, 1>(c, st, N, 1, &pr, lda, nb);
+}
+
+template <class T>
+void hetrd_upper_batch(Ctx& c, hipStream_t st, int N, int nprob, T* const* A, int lda, double* const* d, double* const* e,
+                       T* const* tau, T* const* W, int nb) {
+    if (N <= 0 || nprob <= 0) return;
+    if (nprob == 1) { hetrd_upper<T>(c, st, N, A[0], lda, d[0], e[0], tau[0], W[0], nb); return; }
+    for (int q0 = 0; q0 < nprob; q0 += MAXB) {
+        const int nq = nprob - q0 < MAXB ? nprob - q0 : MAXB;
+        TrdProb<T> pr[MAXB];
+        for (int q = 0; q < nq; ++q) pr[q] = TrdProb<T>{A[q0 + q], d[q0 + q], e[q0 + q], tau[q0 + q], W[q0 + q], trd_scratch<T>(c, N, q)};
+        if (nq == 1) hetrd_lockstep<T, 1>(c, st, N, 1, pr, lda, nb);
+        else hetrd_lockstep<T, MAXB>(c, st, N, nq, pr, lda, nb);
+    }
 }
 
 // Roofline leg: the exact sequence of panel_mv_kernel launches of a full tridiagonalization
@@ -747,23 +802,25 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     *nlaunch = 0; *algo_bytes = 0.0;
     const int nx = TD;
     int np = N;
+    TrdProb<T> pr{A, nullptr, e, tau, W, sc};
     while (np - nb >= nx) {
-        latrd_panel(c, st, sc, np, nb, A, lda, e, tau, W, N, true, nlaunch, algo_bytes);
+        latrd_panel<T, 1>(c, st, 1, &pr, np, nb, lda, N, true, nlaunch, algo_bytes);
         np -= nb;
     }
     int nbr = np - nx;
-    if (nbr > 0) latrd_panel(c, st, sc, np, nbr, A, lda, e, tau, W, N, true, nlaunch, algo_bytes);
+    if (nbr > 0) latrd_panel<T, 1>(c, st, 1, &pr, np, nbr, lda, N, true, nlaunch, algo_bytes);
 }
 
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather) {
     if (n <= 0) return;
     TrdScratch<T> sc = trd_scratch<T>(c, n);
-    PanelArgs<T> a;
+    PanelBatch<T, 1> ab;
+    PanelArgs<T>& a = ab.p[0];
     a.A = const_cast<T*>(A); a.lda = lda; a.W = nullptr; a.ldw = 0; a.np = n + 1; a.nb = 1; a.i = n;
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
     a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0; a.wt = c.p_wt;
     a.gh = hemv_grid(c, n);
-    hipLaunchKernelGGL((panel_mv_kernel<T>), dim3(a.gh), dim3(MVT), 0, st, a, 1, 0);
+    hipLaunchKernelGGL((panel_mv_kernel<T, 1>), dim3(a.gh), dim3(MVT), 0, st, ab, 1, 0);
     if (gather) {
         int nt = (n + HT - 1) / HT;
         hipLaunchKernelGGL((hemv_gather_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, n, nt, (const T*)sc.P, sc.ldp, y);
@@ -773,6 +830,10 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
 
 template void hetrd_upper<double>(Ctx&, hipStream_t, int, double*, int, double*, double*, double*, double*, int);
 template void hetrd_upper<cplx>(Ctx&, hipStream_t, int, cplx*, int, double*, double*, cplx*, cplx*, int);
+template void hetrd_upper_batch<double>(Ctx&, hipStream_t, int, int, double* const*, int, double* const*, double* const*, double* const*,
+                                        double* const*, int);
+template void hetrd_upper_batch<cplx>(Ctx&, hipStream_t, int, int, cplx* const*, int, double* const*, double* const*, cplx* const*,
+                                      cplx* const*, int);
 template <class T> const void* hemv_scratch_touch(Ctx& c, int N, const void** all6) {
     TrdScratch<T> sc = trd_scratch<T>(c, N);
     if (all6) {

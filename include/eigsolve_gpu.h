@@ -98,6 +98,20 @@ int eigsolve_dsygvdx(int N, double *A_d, int lda, double *B_d, int ldb, double *
                      double *w_d, double *work_d, int lwork, double *work_h, int lwork_h, int *iwork_h,
                      int liwork_h, double *Z_h, int ldz_h, double *w_h, int *info, int skip_host_copy);
 
+/* Batch of nprob problems of ONE order (QE k-point style, BASELINE.json configs[4]) solved by one call on the calling thread's
+ * context: the tridiagonalizations run in LOCKSTEP (every per-column launch carries all problems), the other phases problem after
+ * problem.  Arguments as eigsolve_zhegvdx / eigsolve_dsygvdx with one pointer per problem (host arrays of nprob device / host
+ * pointers); the same workspace minima per problem (lwork, lrwork); no host workspaces: the batch driver uses the device
+ * tridiagonal solver ("tridiag" = 1, the default).  info[q] = 0 / -1 per problem; return value -1 if any problem failed.
+ * Per-problem results are bit-identical to the single-problem driver's.  The reference has no counterpart (one problem per
+ * call, zhegvdx_gpu.F90:75); this is the batch extension announced in SURVEY.md 8(b) "Threading". */
+int eigsolve_zhegvdx_batch(int nprob, int N, void *const *A_d, int lda, void *const *B_d, int ldb, void *const *Z_d, int ldz,
+                           int il, int iu, double *const *w_d, void *const *work_d, int lwork, double *const *rwork_d,
+                           int lrwork, void *const *Z_h, int ldz_h, double *const *w_h, int *info, int skip_host_copy);
+int eigsolve_dsygvdx_batch(int nprob, int N, double *const *A_d, int lda, double *const *B_d, int ldb, double *const *Z_d,
+                           int ldz, int il, int iu, double *const *w_d, double *const *work_d, int lwork,
+                           double *const *Z_h, int ldz_h, double *const *w_h, int *info, int skip_host_copy);
+
 /* ---- stage routines (public module procedures of the reference) ---------------------- */
 
 /* zheevd_gpu / dsyevd_gpu (zheevd_gpu.F90:32-134, dsyevd_gpu.F90:32-132): standard problem,

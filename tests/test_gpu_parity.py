@@ -1242,3 +1242,55 @@ def test_real_path_il_quirk_option(env):
         api.set_option("real_il_reference", 0)
     assert info == 0 and np.array_equal(w, w2)
     assert oracle.residual(A, B, w[:m], Zq) <= n * EPS          # columns 1..m hold eigenpairs 1..m
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,m,nprob", [(130, 40, 2), (300, 75, 3), (97, 97, 5), (1100, 200, 2)])
+def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob):
+    """eigsolve_?hegvdx_batch / ?sygvdx_batch: nprob problems of one order, tridiagonalizations in lockstep (every per-column
+    launch carries all problems).  Eigenvalues, eigenvectors, the factor left in B and the preserved strict lower triangle
+    of A must be bit-identical to nprob calls of the single-problem driver (5 problems: more than one lockstep group)."""
+    torch, oracle, api = env
+    probs = [(oracle.gen_spd_fast(n, 8800 + 31 * q + n, cplx), oracle.gen_spd_fast(n, 9900 + 37 * q + n, cplx, shift=float(n)))
+             for q in range(nprob)]
+
+    def dev(M):
+        X = np.triu(M).copy()
+        X[np.tril_indices(n, -1)] = 6.5
+        return api.to_device(X)
+
+    single = []
+    for A, B in probs:
+        Ad, Bd = dev(A), dev(B)
+        info, ws = api.hegvdx(Ad, Bd, 1, m)
+        assert info == 0
+        single.append((ws.w_h.clone(), ws.Z_h.clone(), Ad.clone(), Bd.clone()))
+    pairs = [(dev(A), dev(B)) for A, B in probs]
+    wss = [api.Workspace(n, cplx) for _ in range(nprob)]
+    infos = api.hegvdx_batch(pairs, 1, m, wss)
+    assert infos == [0] * nprob
+    for q in range(nprob):
+        w1, Z1, A1, B1 = single[q]
+        assert torch.equal(wss[q].w_h, w1), q
+        assert torch.equal(wss[q].Z_h[:m], Z1[:m]), q
+        assert torch.equal(wss[q].Z[:m], Z1[:m].cuda()), q
+        assert torch.equal(pairs[q][1], B1) and torch.equal(pairs[q][0], A1), q
+        w = wss[q].w_h.numpy()[:n]
+        Z = np.asfortranarray(api.to_host(wss[q].Z_h, n, m))
+        assert oracle.residual(*probs[q], w, Z) <= n * EPS
+
+
+def test_batch_driver_error_reporting(env):
+    """One problem of the batch has a B that is not positive definite: info = -1 for that problem only, the others are solved."""
+    torch, oracle, api = env
+    n, m = 150, 30
+    A = [oracle.gen_spd_fast(n, 500 + q, True) for q in range(3)]
+    B = [oracle.gen_spd_fast(n, 600 + q, True, shift=float(n)) for q in range(3)]
+    B[1][70, 70] = -3.0
+    pairs = [(api.to_device(np.triu(a)), api.to_device(np.triu(b))) for a, b in zip(A, B)]
+    wss = [api.Workspace(n, True) for _ in range(3)]
+    infos = api.hegvdx_batch(pairs, 1, m, wss)
+    assert infos == [0, -1, 0]
+    for q in (0, 2):
+        Z = np.asfortranarray(api.to_host(wss[q].Z_h, n, m))
+        assert oracle.residual(A[q], B[q], wss[q].w_h.numpy()[:n], Z) <= n * EPS
