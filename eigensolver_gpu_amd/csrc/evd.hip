@@ -591,7 +591,7 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
                            void* const* Z_h, int ldz_h, double* const* w_h, int* info, int skip_host_copy) {
     int rc = guarded(nullptr, [&]() -> int {
         const long n = N;
-        if (nprob < 1 || nprob > 64) { printf(" zhegvdx_gpu batch error: nprob must be in 1..64\n"); return -1; }
+        if (nprob < 1 || nprob > 64 || !info) { printf(" zhegvdx_gpu batch error: nprob must be in 1..64 and info an array of nprob ints\n"); return -1; }
         if (lwork < 2 * 64 * 64 + 65 * n) { printf(" zhegvdx_gpu error: lwork must be at least 2*64*64 + 65*N\n"); return -1; }
         if (lrwork < n) { printf(" zhegvdx_gpu error: lrwork must be at least N\n"); return -1; }
         if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" zhegvdx_gpu error: invalid N/il/iu\n"); return -1; }
@@ -614,7 +614,7 @@ int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double
                            double* const* w_h, int* info, int skip_host_copy) {
     return guarded(nullptr, [&]() -> int {
         const long n = N;
-        if (nprob < 1 || nprob > 64) { printf(" dsygvdx_gpu batch error: nprob must be in 1..64\n"); return -1; }
+        if (nprob < 1 || nprob > 64 || !info) { printf(" dsygvdx_gpu batch error: nprob must be in 1..64 and info an array of nprob ints\n"); return -1; }
         if (lwork < 2 * 64 * 64 + 66 * n) { printf(" dsygvdx_gpu error: lwork must be at least 2*64*64 + 66*N\n"); return -1; }
         if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" dsygvdx_gpu error: invalid N/il/iu\n"); return -1; }
         Ctx& c = ctx();
