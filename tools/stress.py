@@ -29,8 +29,9 @@ for case in range(cases):
     il = int(rng.integers(1, n + 1)); iu = int(rng.integers(il, n + 1))
     if rng.random() < 0.5: il = 1
     m = iu - il + 1
-    opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 3)),
-            "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256])), "trd_nb": int(rng.choice([64, 32, 17]))}
+    opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 4)),
+            "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256, 256, 512, 1024])),
+            "trd_nb": int(rng.choice([64, 32, 17])), "potrf": int(rng.choice([1, 1, 0]))}
     for k, v in opts.items(): assert api.set_option(k, v) == 0
     A = gen_spd(n, 100 + case, cplx)
     B = gen_spd(n, 200 + case, cplx, shift=float(n))
@@ -46,5 +47,6 @@ for case in range(cases):
     print("%s case %3d n=%4d %s il=%4d iu=%4d %s res=%.2e orth=%.2e" % ("ok " if ok else "BAD", case, n, "z" if cplx else "d", il, iu, opts, res, orth), flush=True)
 for k in ("tridiag", "gst"): api.set_option(k, -1)
 for k in ("bt_nb", "gst_thr", "trsm_base", "trd_nb"): api.set_option(k, 0)
+api.set_option("potrf", 1)
 print("%d cases, %d bad, %.1f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
