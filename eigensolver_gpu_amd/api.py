@@ -396,15 +396,24 @@ def hetrd_mv_sweep(A_d, nb=0, reps=1):
     return {"ms_total": ms.value, "launches": nl.value, "algo_bytes": by.value}
 
 
-def larft(A_d, tau_d, nb=128):
+def bt_block(nb, N):
+    """Reflectors per block the library uses for a requested width nb (bt_norm_nb in evd.hip): 64 / 128 / 256 / 512, no
+    wider than the problem needs."""
+    nb = 512 if nb >= 512 else 256 if nb >= 256 else 128 if nb >= 128 else 64
+    while nb > 64 and nb // 2 >= N:
+        nb //= 2
+    return nb
+
+
+def larft(A_d, tau_d, nb=256):
     """All T factors (zlarft_gpu, zheevd_gpu.F90:136-176) of a tridiagonalized A_d.  Returns a numpy array
     (nblk, ldt, ldt) of lower-triangular blocks (math orientation)."""
     import torch
     _sync()
     N = A_d.shape[0]
     k = N - 1
-    nbe = min(nb if nb == 64 else 128, N)
-    ldt = 128 if nbe > 64 else 64
+    nbe = bt_block(nb, N)
+    ldt = nbe
     nblk = max(1, (k + nbe - 1) // nbe)
     T = torch.zeros((nblk, ldt, ldt), dtype=A_d.dtype, device="cuda")
     name = "eigsolve_zlarft" if _pre(A_d) == "z" else "eigsolve_dlarft"
@@ -413,7 +422,7 @@ def larft(A_d, tau_d, nb=128):
     return T.cpu().numpy().transpose(0, 2, 1)
 
 
-def unmtr(A_d, tau_d, Z_d, m, nb=128):
+def unmtr(A_d, tau_d, Z_d, m, nb=256):
     """Z(:, :m) <- Q Z with Q from the reflectors in upper(A_d) (the zlarft_gpu / zlarfb_gpu loop, zheevd_gpu.F90:113-131)."""
     _sync()
     N = A_d.shape[0]

@@ -56,6 +56,16 @@ struct Epi {
                         //                       2 = A operand (needs ONE tile along N, N <= 64)
 };
 
+// Strided batch descriptor: entry zb = 0..count-1 uses A.p + zb*sA, Bt.p + zb*sB, C + zb*sC, mask offsets + zb*dMoff*,
+// K + zb*dK, and M, N clipped to cap* - zb*dcap (INT_MAX = no clipping).  `splits` is filled in by gemm_batched.
+struct GemmBatch {
+    int count = 0;
+    int splits = 1;
+    long sA = 0, sB = 0, sC = 0;
+    int dMoffA = 0, dMoffB = 0, dK = 0;
+    int capM = INT_MAX, capN = INT_MAX, dcap = 0;
+};
+
 // C(MxN) = alpha * A * B + beta * C.
 template <class T>
 void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
@@ -66,6 +76,11 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
 template <class T>
 void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt,
                  T beta, T* C, int ldc, int kchunk, Epi epi = Epi());
+
+// bt.count products of one shape in one launch; kchunk > 0 additionally splits K (partials summed in a fixed order).
+template <class T>
+void gemm_batched(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
+                  T* C, int ldc, Epi epi, GemmBatch bt, int kchunk = 0);
 
 // C(upper) -= V W^H + W V^H  (trans='N'), V,W n x k.
 template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc);

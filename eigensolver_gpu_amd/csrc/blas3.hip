@@ -35,6 +35,7 @@ template <class T> struct GemmArgs {
     T* P;            // split-K partial output (M x N per split, ld = M)
     size_t pstride;
     int tri;         // 1: 1-D grid over the tiles of the stored triangle only (see tile_of)
+    GemmBatch bt;    // count > 0: blockIdx.z = batch entry * bt.splits + K-split (gemm_fast_kernel only)
 };
 
 // Tile owned by this workgroup.  Triangular outputs (epi.uplo) on a square tile grid are launched as a 1-D grid
@@ -53,7 +54,7 @@ template <class T> __device__ __forceinline__ void tile_of(const GemmArgs<T>& g,
 
 template <class T>
 __device__ __forceinline__ T fetch(const Operand<T>& o, int idx, int k, int nidx, int kend) {
-    // branch-free (see fetch_fast): always load from a clamped valid address, then select
+    // branch-free: always load from a clamped valid address, then select
     bool keep = idx < nidx && k < kend, one = false;
     const bool seg2 = k >= o.k1;
     const T* p = seg2 ? o.p2 : o.p;
@@ -283,43 +284,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
 
 // ------------------------------------------------------------------------------------------------
 // gemm_fast_kernel: same math and LDS layouts as gemm_kernel, restructured for throughput:
-//  * per-thread element descriptors (pointer, stored coordinates, validity) are computed ONCE;
-//    a stage costs one pointer bump, a mask compare and a load per element instead of the generic
-//    fetch() (which re-derives everything and was ~half of a stage's time);
+//  * per-thread element descriptors (stored coordinates, validity, LDS offset) are computed ONCE; a stage's global
+//    loads are raw (clamped address only) and the mask / conjugation / zero-fill are applied one slab later, when
+//    the registers are written to LDS -- so the loads really stay in flight across the MFMAs of a slab;
 //  * K-concatenated operands (her2k) run as two phases over (p, ld) then (p2, ld2) -- the host
 //    guarantees k1 % BK == 0, otherwise the generic kernel is used;
 //  * LDS is double-buffered: the store of slab k+1 and the global loads of slab k+2 are issued
 //    before the MFMAs of slab k, ONE barrier per stage.
 // ------------------------------------------------------------------------------------------------
-template <class T> struct ElemDesc {
-    const T* p;   // address of X(idx, k = kloc) of the current segment
-    int sidx;     // stored-row (trans=0) / stored-col (trans=1) coordinate = global idx
-    int kloc;     // k offset of this element inside a slab
-    bool ok;      // idx in range
-};
-
-// Branch-free: the load is ALWAYS issued (from a clamped, valid address) and the value selected
-// afterwards.  With `if (ok) v = *p` hipcc puts every load in its own basic block followed by
-// s_waitcnt vmcnt(0) -- the loads of a slab then complete one after the other (measured: 66 % of
-// the wave cycles in waits).
-template <class T, bool MASKED>
-__device__ __forceinline__ T fetch_fast(const Operand<T>& o, const ElemDesc<T>& e, const T* safe, long kstride, int k, int kend) {
-    const int kk = k + e.kloc;
-    bool keep = e.ok && kk < kend, one = false;
-    if (MASKED && o.mask != M_NONE) {
-        const int sr = o.trans ? kk : e.sidx;
-        const int sc = o.trans ? e.sidx : kk;
-        const int d = sr - sc - o.moff;
-        const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
-        one = keep && (o.mask == M_UNITTRAP) && (d == 0);
-        keep = keep && km;
-    }
-    const T* addr = keep ? e.p + (long)k * kstride : safe;
-    T v = *addr;
-    if (o.conj) v = conj_(v);
-    return keep ? v : (one ? Tr<T>::one() : Tr<T>::zero());
-}
-
 template <class T, int BM, int BN, int TA, int TB, int BK, bool MASKED>
 __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
     constexpr bool CX = Tr<T>::cx;
@@ -334,15 +306,29 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
     __shared__ double sm[2 * STG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // strided batch: entry zb works on operands / output shifted by constant strides, with its own K, mask offsets and
+    // (clipped) M, N -- all wave-uniform
+    const int pld = g.M;          // leading dimension of the split-K partial blocks
+    int zs = blockIdx.z;
+    if (g.bt.count > 0) {
+        const int zb = blockIdx.z / g.bt.splits;
+        zs = blockIdx.z - zb * g.bt.splits;
+        g.A.p += (long)zb * g.bt.sA; g.B.p += (long)zb * g.bt.sB; g.C += (long)zb * g.bt.sC;
+        g.A.moff += zb * g.bt.dMoffA; g.B.moff += zb * g.bt.dMoffB;
+        g.K += zb * g.bt.dK;
+        g.M = min(g.M, g.bt.capM - zb * g.bt.dcap);
+        g.N = min(g.N, g.bt.capN - zb * g.bt.dcap);
+    }
     int tbx, tby;
     tile_of(g, tbx, tby);
     const int i0 = tbx * BM, j0 = tby * BN;
     if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
     if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
+    if (i0 >= g.M || j0 >= g.N) return;      // (clipped batch entries)
 
     int kbeg = 0, kend = g.K;
     if (g.kchunk > 0) {
-        kbeg = blockIdx.z * g.kchunk;
+        kbeg = zs * g.kchunk;
         kend = min(g.K, kbeg + g.kchunk);
     }
     trim_k(g.A, i0, BM, kbeg, kend);
@@ -359,16 +345,20 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
             for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
 
     // ---- element descriptors -----------------------------------------------------------------------
-    ElemDesc<T> ea[EA], eb[EB];
+    // Per thread and element: global idx, k offset inside a slab, validity, LDS offset.  A slab's global loads are RAW
+    // (clamped address, nothing else); mask / conjugation / zero-fill are applied when the registers go to LDS, one
+    // slab later.  (With the select next to the load -- the first form of this kernel -- hipcc waits for the loads right
+    // where they are issued: s_waitcnt vmcnt(0) in front of the MFMAs of EVERY slab, i.e. one exposed memory round trip
+    // per slab; found in the ISA in round 3.)
+    int sia[EA], kla[EA], sib[EB], klb[EB];
+    bool oka[EA], okb[EB];
     int offa[EA], offb[EB];   // LDS offsets inside a stage
-    const long ksa = g.A.trans ? 1 : (long)g.A.ld, ksb = g.B.trans ? 1 : (long)g.B.ld;
 #pragma unroll
     for (int e = 0; e < EA; ++e) {
         int idx, k;
         if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
         else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-        ea[e].sidx = i0 + idx; ea[e].kloc = k; ea[e].ok = (i0 + idx) < g.M;
-        ea[e].p = g.A.trans ? g.A.p + (size_t)k + (size_t)(i0 + idx) * g.A.ld : g.A.p + (size_t)(i0 + idx) + (size_t)k * g.A.ld;
+        sia[e] = i0 + idx; kla[e] = k; oka[e] = (i0 + idx) < g.M;
         offa[e] = TA == 0 ? k * LDA + idx : idx * LDA + k;
     }
 #pragma unroll
@@ -376,47 +366,91 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
         int idx, k;
         if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
         else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-        eb[e].sidx = j0 + idx; eb[e].kloc = k; eb[e].ok = (j0 + idx) < g.N;
-        eb[e].p = g.B.trans ? g.B.p + (size_t)k + (size_t)(j0 + idx) * g.B.ld : g.B.p + (size_t)(j0 + idx) + (size_t)k * g.B.ld;
+        sib[e] = j0 + idx; klb[e] = k; okb[e] = (j0 + idx) < g.N;
         offb[e] = NPL * ASZ + (TB == 0 ? k * LDB + idx : idx * LDB + k);
     }
     // second segment (K-concatenation): same descriptors on (p2, ld2), logical k >= k1
     const bool cat = g.A.k1 != INT_MAX;
     const int k1 = cat ? g.A.k1 : kend;   // host guarantees A.k1 == B.k1 and k1 % BK == 0
 
+    // keep / unit-diagonal predicates of one element (kk = k inside its segment, ke = end of the segment).  `need` is
+    // wave-uniform: false when the mask cannot touch any element of the current (tile, slab) -- the mask arithmetic is
+    // then skipped altogether (measured: a unit-trapezoid operand evaluated per element costs 20 % of the launch, and
+    // only the few tile-slabs on the diagonal band of a triangular / trapezoidal operand need it).
+    auto pred = [&](const Operand<T>& o, int trans, int sidx, bool ok, int kk, int ke, bool need, bool& one) -> bool {
+        bool keep = ok && kk < ke;
+        one = false;
+        if (MASKED && need) {
+            const int sr = trans ? kk : sidx;
+            const int sc = trans ? sidx : kk;
+            const int d = sr - sc - o.moff;
+            const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
+            one = keep && (o.mask == M_UNITTRAP) && (d == 0);
+            keep = keep && km;
+        }
+        return keep;
+    };
+    // does the mask of operand o affect the slab [kl, kl + BK) of the tile rows/columns [x0, x0 + bs)?  (entries it zeroes
+    // everywhere were removed by trim_k; here: is every entry kept unchanged?)
+    auto mask_active = [&](const Operand<T>& o, int trans, int x0, int bs, int kl) -> bool {
+        if (!MASKED || o.mask == M_NONE) return false;
+        const int dmin = trans ? kl - (x0 + bs - 1) : x0 - (kl + BK - 1);      // min / max of (stored row - stored col)
+        const int dmax = trans ? kl + BK - 1 - x0 : x0 + bs - 1 - kl;
+        if (o.mask == M_UPPER) return dmax > 0;
+        if (o.mask == M_SUPPER) return dmax >= 0;
+        if (o.mask == M_LOWER) return dmin < 0;
+        return dmax - o.moff >= 0;                                             // M_UNITTRAP
+    };
+
     T ra[EA], rb[EB];
+    int pkl = 0, pke = 0;     // segment-local slab origin and segment end of the slab held in ra / rb
+    bool pna = false, pnb = false;   // mask_active of that slab
     auto gload = [&](int k0) {
-        if (!cat || k0 < k1) {
+        const bool s2 = k0 >= k1;     // (never true without K-concatenation: k1 = kend)
+        const T* pa = s2 ? g.A.p2 : g.A.p;
+        const T* pb = s2 ? g.B.p2 : g.B.p;
+        const long la = s2 ? g.A.ld2 : g.A.ld, lb = s2 ? g.B.ld2 : g.B.ld;
+        pkl = s2 ? k0 - k1 : k0;
+        pke = s2 ? kend - k1 : min(kend, k1);
+        pna = mask_active(g.A, TA, i0, BM, pkl);
+        pnb = mask_active(g.B, TB, j0, BN, pkl);
 #pragma unroll
-            for (int e = 0; e < EA; ++e) ra[e] = fetch_fast<T, MASKED>(g.A, ea[e], g.A.p, ksa, k0, min(kend, k1));
+        for (int e = 0; e < EA; ++e) {
+            bool one;
+            const int kk = pkl + kla[e];
+            const bool keep = pred(g.A, TA, sia[e], oka[e], kk, pke, pna, one);
+            const T* addr = TA ? pa + (size_t)kk + (size_t)sia[e] * la : pa + (size_t)sia[e] + (size_t)kk * la;
+            ra[e] = *(keep ? addr : pa);
+        }
 #pragma unroll
-            for (int e = 0; e < EB; ++e) rb[e] = fetch_fast<T, MASKED>(g.B, eb[e], g.B.p, ksb, k0, min(kend, k1));
-        } else {
-            const long ks2a = g.A.trans ? 1 : (long)g.A.ld2, ks2b = g.B.trans ? 1 : (long)g.B.ld2;
-#pragma unroll
-            for (int e = 0; e < EA; ++e) {
-                ElemDesc<T> d = ea[e];
-                d.p = g.A.trans ? g.A.p2 + (size_t)d.kloc + (size_t)d.sidx * g.A.ld2 : g.A.p2 + (size_t)d.sidx + (size_t)d.kloc * g.A.ld2;
-                ra[e] = fetch_fast<T, MASKED>(g.A, d, g.A.p2, ks2a, k0 - k1, kend - k1);
-            }
-#pragma unroll
-            for (int e = 0; e < EB; ++e) {
-                ElemDesc<T> d = eb[e];
-                d.p = g.B.trans ? g.B.p2 + (size_t)d.kloc + (size_t)d.sidx * g.B.ld2 : g.B.p2 + (size_t)d.sidx + (size_t)d.kloc * g.B.ld2;
-                rb[e] = fetch_fast<T, MASKED>(g.B, d, g.B.p2, ks2b, k0 - k1, kend - k1);
-            }
+        for (int e = 0; e < EB; ++e) {
+            bool one;
+            const int kk = pkl + klb[e];
+            const bool keep = pred(g.B, TB, sib[e], okb[e], kk, pke, pnb, one);
+            const T* addr = TB ? pb + (size_t)kk + (size_t)sib[e] * lb : pb + (size_t)sib[e] + (size_t)kk * lb;
+            rb[e] = *(keep ? addr : pb);
         }
     };
     auto lstore = [&](double* st) {
 #pragma unroll
         for (int e = 0; e < EA; ++e) {
-            st[offa[e]] = real_(ra[e]);
-            if (CX) st[ASZ + offa[e]] = imag_(ra[e]);
+            bool one;
+            const bool keep = pred(g.A, TA, sia[e], oka[e], pkl + kla[e], pke, pna, one);
+            T v = ra[e];
+            if (g.A.conj) v = conj_(v);
+            v = sel(keep, v, sel(one, Tr<T>::one(), Tr<T>::zero()));
+            st[offa[e]] = real_(v);
+            if (CX) st[ASZ + offa[e]] = imag_(v);
         }
 #pragma unroll
         for (int e = 0; e < EB; ++e) {
-            st[offb[e]] = real_(rb[e]);
-            if (CX) st[BSZ + offb[e]] = imag_(rb[e]);
+            bool one;
+            const bool keep = pred(g.B, TB, sib[e], okb[e], pkl + klb[e], pke, pnb, one);
+            T v = rb[e];
+            if (g.B.conj) v = conj_(v);
+            v = sel(keep, v, sel(one, Tr<T>::one(), Tr<T>::zero()));
+            st[offb[e]] = real_(v);
+            if (CX) st[BSZ + offb[e]] = imag_(v);
         }
     };
 
@@ -515,7 +549,7 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
                 if (g.epi.uplo == 2 && gi < gj) ok = false;
                 T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
                 if (g.kchunk > 0) {
-                    if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
+                    if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * pld] = v;
                 } else {
                     T out = g.alpha * v;
                     if (use_c) out = out + g.beta * cv[a][b][r];
@@ -529,10 +563,16 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
 
 template <class T>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int splits, const T* P, size_t pstride, T alpha,
-                                                            T beta, T* C, int ldc, Epi epi) {
+                                                            T beta, T* C, int ldc, Epi epi, GemmBatch bt) {
     size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (size_t)M * N) return;
     int i = (int)(id % M), j = (int)(id / M);
+    if (bt.count > 0) {           // batch entry blockIdx.y: its partial blocks, its output, its clipped extent
+        const int zb = blockIdx.y;
+        P += (size_t)zb * splits * pstride;
+        C += (long)zb * bt.sC;
+        if (i >= bt.capM - zb * bt.dcap || j >= bt.capN - zb * bt.dcap) return;
+    }
     if (epi.uplo == 1 && i > j) return;
     if (epi.uplo == 2 && i < j) return;
     T s = Tr<T>::zero();
@@ -630,7 +670,7 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
           int ldc, Epi epi) {
     GemmArgs<T> g;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
-    g.kchunk = 0; g.P = nullptr; g.pstride = 0;
+    g.kchunk = 0; g.P = nullptr; g.pstride = 0; g.bt = GemmBatch();
     // Tile quantisation: a grid whose 64x64 tiles do not fill the resident workgroups (2 per CU) a whole number of
     // times leaves most of the chip idle in the last round (an upper-triangle update of order 2048 is 528 tiles on
     // 512 slots: 2 rounds for 1.03 rounds of work).  When K is long enough, split it so that the work items are
@@ -664,7 +704,7 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
                     dispatch_gemm(c, st, g, splits);
                     size_t total = (size_t)M * N;
                     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N,
-                                       splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi);
+                                       splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
                     EIG_HIP(hipGetLastError());
                     return;
                 }
@@ -686,14 +726,44 @@ void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Ope
     }
     GemmArgs<T> g;
     g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
-    g.kchunk = kchunk;
+    g.kchunk = kchunk; g.bt = GemmBatch();
     g.pstride = (size_t)M * N;
     g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits);
     dispatch_gemm(c, st, g, splits);
     size_t total = (size_t)M * N;
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, splits,
-                       (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi);
+                       (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
     EIG_HIP(hipGetLastError());
+}
+
+// Strided batch of `bt.count` products of one shape in ONE launch (optionally split along K): the many small independent
+// products of the back-transformation's T factors (zheevd_gpu.F90:136-176 builds them one reflector block at a time).
+template <class T>
+void gemm_batched(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>& A, const Operand<T>& Bt, T beta,
+                  T* C, int ldc, Epi epi, GemmBatch bt, int kchunk) {
+    if (M <= 0 || N <= 0 || bt.count <= 0) return;
+    const int Kmax = K + (bt.dK > 0 ? (bt.count - 1) * bt.dK : 0);
+    int splits = 1;
+    if (kchunk > 0) {
+        kchunk = ((kchunk + BKS - 1) / BKS) * BKS;
+        splits = (Kmax + kchunk - 1) / kchunk;
+    }
+    GemmArgs<T> g;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.A = A; g.B = Bt; g.C = C; g.ldc = ldc; g.epi = epi;
+    g.kchunk = splits > 1 ? kchunk : 0; g.P = nullptr; g.pstride = 0;
+    bt.splits = splits;
+    g.bt = bt;
+    if (splits > 1) {
+        g.pstride = (size_t)M * N;
+        g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits * bt.count);
+    }
+    dispatch_gemm(c, st, g, splits * bt.count);
+    if (splits > 1) {
+        size_t total = (size_t)M * N;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256), bt.count), dim3(256), 0, st, M, N,
+                           splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, bt);
+        EIG_HIP(hipGetLastError());
+    }
 }
 
 template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc) {
@@ -1633,6 +1703,8 @@ template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* 
     template void gemm_splitk<T>(Ctx&, hipStream_t, int, int, int, T, const Operand<T>&, const Operand<T>&, T, T*, int,  \
                                  int, Epi);                                                                              \
     template void her2k_un<T>(Ctx&, hipStream_t, int, int, const T*, int, const T*, int, T*, int);                       \
+    template void gemm_batched<T>(Ctx&, hipStream_t, int, int, int, T, const Operand<T>&, const Operand<T>&, T, T*, int, \
+                                  Epi, GemmBatch, int);                                                                  \
     template void potrf_upper<T>(Ctx&, hipStream_t, int, T*, int);                                                       \
     template void build_invU<T>(Ctx&, hipStream_t, int, const T*, int);                                                  \
     template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \

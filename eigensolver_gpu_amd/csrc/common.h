@@ -103,9 +103,10 @@ enum Phase { PH_POTRF = 0, PH_GST, PH_TRD, PH_STEDC, PH_BT, PH_TRSM, PH_D2H, PH_
 // the host dstedc at N=4096); EIGSOLVE_TRIDIAG=host / eigsolve_set_option("tridiag", 0) restores the
 // reference behaviour (host LAPACK).
 constexpr int kTridiagDefault = 1;
-// Reflectors per block in the back-transformation: 64 (the reference's larfb width, zheevd_gpu.F90:113-131) or
-// 128 = two 64-blocks with a merged T factor (twice the K of the rank-k update: twice the arithmetic intensity).
-constexpr int kBtNbDefault = 128;
+// Reflectors per block in the back-transformation: 64 (the reference's larfb width, zheevd_gpu.F90:113-131), or 128 / 256 / 512 =
+// 64-blocks whose T factors are merged pairwise (bt_build_T in evd.hip): K of the rank-k updates grows with the block.
+constexpr int kBtNbDefault = 256;
+inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 0;
 // Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
@@ -153,6 +154,7 @@ struct Ctx {
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
+    int trace_marks = 0;     // EIGSOLVE_TRACE_MARKS=1: marker kernels at the phase boundaries (profiling aid, see evd.hip)
 
     template <class T> T* scratch(const char* name, size_t count) {
         return reinterpret_cast<T*>(scratch_bytes(name, count * sizeof(T)));
@@ -160,6 +162,7 @@ struct Ctx {
     void* scratch_bytes(const char* name, size_t bytes);
     void* host_scratch_bytes(const char* name, size_t bytes);
     void release();
+    void drop_graphs();   // forget captured launch sequences (an option they bake in has changed)
 };
 
 Ctx& ctx();  // lazily created for the current device + calling thread

@@ -82,17 +82,23 @@ void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
     return s.first;
 }
 
+void Ctx::drop_graphs() {
+    if (graphs.empty()) return;
+    if (s1) (void)hipStreamSynchronize(s1);
+    for (auto& kv : graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    graphs.clear();
+}
+
 void Ctx::release() {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return;   // runtime already gone (process teardown): nothing to free
     if (dev >= 0 && cur != dev) (void)hipSetDevice(dev);
     if (s1) (void)hipStreamSynchronize(s1);
     if (s2) (void)hipStreamSynchronize(s2);
-    for (auto& kv : graphs) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-    }
-    graphs.clear();
+    drop_graphs();
     for (auto& kv : slots)
         if (kv.second.first) (void)hipFree(kv.second.first);
     slots.clear();
@@ -119,6 +125,7 @@ static void init_options(Ctx& c) {
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
     if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_TRACE_MARKS")) c.trace_marks = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c.bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c.hemv_blocks = atoi(e);
@@ -134,8 +141,7 @@ static void init_options(Ctx& c) {
     if (c.gst_thr < 256) c.gst_thr = 256;
     if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c.tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
     if (c.trd_nb < 1 || c.trd_nb > 64) c.trd_nb = 64;
-    if (c.bt_nb < 1 || c.bt_nb > 128) c.bt_nb = kBtNbDefault;
-    if (c.bt_nb > 64) c.bt_nb = 128;
+    c.bt_nb = norm_bt_nb(c.bt_nb);
     if (c.hemv_blocks > kHemvBlocksMax) c.hemv_blocks = kHemvBlocksMax;
 }
 
@@ -301,10 +307,10 @@ int eigsolve_set_option(const char* name, int value) {
         eig::Ctx& c = eig::ctx();
         std::string s(name ? name : "");
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
-        else if (s == "bt_nb") c.bt_nb = (value <= 0 || value > 128) ? eig::kBtNbDefault : (value > 64 ? 128 : value);
+        else if (s == "bt_nb") c.bt_nb = eig::norm_bt_nb(value);
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
-        else if (s == "hemv_balance") c.hemv_balance = value != 0;
-        else if (s == "p_wt") c.p_wt = value != 0;
+        else if (s == "hemv_balance") { c.hemv_balance = value != 0; c.drop_graphs(); }   // baked into captured launch sequences
+        else if (s == "p_wt") { c.p_wt = value != 0; c.drop_graphs(); }
         else if (s == "real_il_reference") c.real_il_reference = value > 0;
         else if (s == "graph") c.use_graph = value > 0;
         else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);

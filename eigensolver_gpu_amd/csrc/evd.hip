@@ -29,9 +29,9 @@ template <class T> __global__ void __launch_bounds__(256) widen_kernel(int n, in
 template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, int nb2, T* Tall, int ldt, const T* tau_all) {
     __shared__ T t[64][65];  // t[col][row]
     const int tx = threadIdx.x;
-    // reflector blocks of nb2 <= 128 = up to two 64-wide halves, one workgroup per half
-    const int halves = nb2 > 64 ? 2 : 1;
-    const int b = blockIdx.x / halves, sub = blockIdx.x % halves;
+    // reflector blocks of nb2 <= 512 = up to eight 64-wide parts, one workgroup per part
+    const int parts = (nb2 + 63) / 64;
+    const int b = blockIdx.x / parts, sub = blockIdx.x % parts;
     const int ibb = (k - b * nb2 < nb2) ? k - b * nb2 : nb2;   // reflectors in block b
     const int K = (ibb - sub * 64 < 64) ? ibb - sub * 64 : 64;
     if (K <= 0) return;
@@ -66,11 +66,12 @@ template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, 
 // 4x4 block of the 64x64 result; X = S10 T0 goes through LDS.
 template <class T> __global__ void __launch_bounds__(256) merge_T_kernel(int k, int nb2, T* Tall, int ldt) {
     __shared__ T X[64][65];   // X[c][r]
-    const int b = blockIdx.x;
+    const int pairs = nb2 / 128;                 // 128-pairs per reflector block (nb2 = 128, 256, 512)
+    const int b = blockIdx.x / pairs, pr = blockIdx.x % pairs;
     const int ibb = (k - b * nb2 < nb2) ? k - b * nb2 : nb2;
-    const int K1 = ibb - 64;   // rows of the (1,0) block
+    const int K1 = min(64, ibb - pr * 128 - 64);   // rows of the pair's (1,0) block
     if (K1 <= 0) return;
-    T* Tb = Tall + (size_t)b * ldt * ldt;
+    T* Tb = Tall + (size_t)b * ldt * ldt + (size_t)pr * 128 * (1 + ldt);
     const T* T0 = Tb;
     T* S10 = Tb + 64;
     const T* T1 = Tb + (size_t)64 * (1 + ldt);
@@ -127,41 +128,76 @@ template <class T> __global__ void __launch_bounds__(256) merge_T_kernel(int k, 
 // (zheevd_gpu.F90:113-131).  All T factors are built first (they do not depend on C), then each
 // block costs three MFMA launches.  V's bottom square is masked on the fly (unit upper
 // triangular) instead of the reference's stash / zero / restore of A (:154-164, :203-211).
+static inline int bt_norm_nb(int nb2, int N) {
+    nb2 = nb2 >= 512 ? 512 : (nb2 >= 256 ? 256 : (nb2 >= 128 ? 128 : 64));
+    while (nb2 > 64 && nb2 / 2 >= N) nb2 /= 2;     // small problems: no wider than needed
+    return nb2;
+}
+
+// All T factors of the reflector blocks (blocks of nb2 = 64 / 128 / 256 / 512 reflectors), in a fixed number of launches:
+//   1. Gram blocks S_b = V_b^H V_b (lower) for ALL blocks in one strided-batch split-K launch (+ one reduce);
+//   2. the 64x64 diagonal parts by the recurrence of finish_T_block_kernel (zheevd_gpu.F90:215-279), one workgroup each;
+//   3. pairwise merges 64 -> 128 (merge_T_kernel), 128 -> 256, 256 -> 512 (two batched MFMA products per level):
+//        (I - V1 T1 V1^H)(I - V0 T0 V0^H) = I - [V0 V1] [[T0, 0], [T10, T1]] [V0 V1]^H,   T10 = -T1 (V1^H V0) T0,
+//      where V1^H V0 is the (1,0) block of S_b already sitting in the buffer.
+// Wider blocks = higher K of the rank-nb2 updates in bt_apply (the MFMA engine reaches ~50 TFLOP/s at K = 256 against ~38
+// at K = 128) and half / a quarter of the launches, for (nb2 / N) extra flops in T.
 template <class T>
 static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const T* tau, int nb2) {
     const int k = N - 1;
     if (k <= 0) return;
-    if (nb2 > N) nb2 = N;
+    nb2 = bt_norm_nb(nb2, N);
     const int nblk = (k + nb2 - 1) / nb2;
-    const int ldt = nb2 > 64 ? 128 : 64;
+    const int ldt = nb2;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
-    for (int b = 0; b < nblk; ++b) {
-        int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
-        const T* V = A + (size_t)(i + 1) * lda;
-        T* Tb = Tall + (size_t)b * ldt * ldt;
-        Operand<T> Va = op_plain(V, lda, 1, 1);  // (r,p) -> conj(V(p,r))
-        Va.mask = M_UNITTRAP; Va.moff = mi - ib;
-        Operand<T> Vb = op_plain(V, lda, 1, 0);  // Bt(j,p) = V(p,j)
-        Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
+    EIG_HIP(hipMemsetAsync(Tall, 0, sizeof(T) * (size_t)nblk * ldt * ldt, st));
+    {
+        const T* V = A + (size_t)lda;                 // block b: V + b*nb2*lda, rows 0..mi-1, mi = min((b+1) nb2, k)
+        Operand<T> Va = op_plain(V, lda, 1, 1);       // (r,p) -> conj(V(p,r))
+        Va.mask = M_UNITTRAP; Va.moff = 0;            // unit diagonal at row b*nb2 + column (moff = mi - ib = b*nb2)
+        Operand<T> Vb = op_plain(V, lda, 1, 0);       // Bt(j,p) = V(p,j)
+        Vb.mask = M_UNITTRAP; Vb.moff = 0;
         Epi e; e.uplo = 2;
-        gemm_splitk<T>(c, st, ib, ib, mi, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tb, ldt, 256, e);
+        GemmBatch bt;
+        bt.count = nblk; bt.sA = bt.sB = (long)nb2 * lda; bt.sC = (long)ldt * ldt;
+        bt.dMoffA = bt.dMoffB = nb2; bt.dK = nb2; bt.capM = bt.capN = k; bt.dcap = nb2;
+        const int ib0 = k < nb2 ? k : nb2;
+        gemm_batched<T>(c, st, ib0, ib0, ib0, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tall, ldt, e, bt, 256);
     }
-    const int halves = nb2 > 64 ? 2 : 1;
-    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk * halves), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
-    if (halves == 2) hipLaunchKernelGGL((merge_T_kernel<T>), dim3(nblk), dim3(256), 0, st, k, nb2, Tall, ldt);
+    const int parts = nb2 / 64;
+    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk * parts), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
+    if (nb2 >= 128) hipLaunchKernelGGL((merge_T_kernel<T>), dim3(nblk * (nb2 / 128)), dim3(256), 0, st, k, nb2, Tall, ldt);
     EIG_HIP(hipGetLastError());
+    for (int s_ = 128; 2 * s_ <= nb2; s_ *= 2) {      // merge pairs of s_-blocks; everything beyond the last reflector is zero
+        T* X = c.scratch<T>("bt_X", (size_t)nblk * s_ * s_);
+        for (int mg = 0; mg < nb2 / (2 * s_); ++mg) {
+            T* base = Tall + (size_t)mg * 2 * s_ * (1 + ldt);
+            GemmBatch bt;
+            bt.count = nblk; bt.sA = bt.sB = (long)ldt * ldt; bt.sC = (long)s_ * s_;
+            Operand<T> S10 = op_plain((const T*)(base + s_), ldt, 0, 0);
+            Operand<T> T0 = op_plain((const T*)base, ldt, 1, 0);              // Bt(j,p) = T0(p,j), T0 lower
+            T0.mask = M_LOWER;
+            gemm_batched<T>(c, st, s_, s_, s_, Tr<T>::one(), S10, T0, Tr<T>::zero(), X, s_, Epi(), bt);          // X = S10 T0
+            GemmBatch b2;
+            b2.count = nblk; b2.sA = (long)ldt * ldt; b2.sB = (long)s_ * s_; b2.sC = (long)ldt * ldt;
+            Operand<T> T1 = op_plain((const T*)(base + (size_t)s_ * (1 + ldt)), ldt, 0, 0);
+            T1.mask = M_LOWER;
+            gemm_batched<T>(c, st, s_, s_, s_, Tr<T>::make(-1.0, 0.0), T1, opB('N', (const T*)X, s_), Tr<T>::zero(), base + s_, ldt,
+                            Epi(), b2);                                                                          // T10 = -T1 X
+        }
+    }
 }
 
 template <class T>
 static void bt_apply(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, T* Z, int ldz, int nb2) {
     const int k = N - 1;
     if (k <= 0 || m <= 0) return;
-    if (nb2 > N) nb2 = N;
+    nb2 = bt_norm_nb(nb2, N);
     const int nblk = (k + nb2 - 1) / nb2;
-    const int ldt = nb2 > 64 ? 128 : 64;
+    const int ldt = nb2;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
-    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * 128);
-    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * 128);
+    T* Wk = c.scratch<T>("bt_Wk", (size_t)m * nb2);
+    T* Wk2 = c.scratch<T>("bt_Wk2", (size_t)m * nb2);
     for (int b = 0; b < nblk; ++b) {
         int i = b * nb2, ib = (k - i < nb2) ? k - i : nb2, mi = i + ib;
         const T* V = A + (size_t)(i + 1) * lda;
@@ -170,12 +206,11 @@ static void bt_apply(Ctx& c, hipStream_t st, int N, int m, const T* A, int lda, 
         Operand<T> Ca = op_plain((const T*)Z, ldz, 1, 1);
         Operand<T> Vb = op_plain(V, lda, 1, 0);
         Vb.mask = M_UNITTRAP; Vb.moff = mi - ib;
-        static const int bt_fill = getenv("EIGSOLVE_BT_FILL") ? atoi(getenv("EIGSOLVE_BT_FILL")) : 2;   // workgroups per CU aimed at
-        static const int bt_kmin = getenv("EIGSOLVE_BT_KMIN") ? atoi(getenv("EIGSOLVE_BT_KMIN")) : 128;
         int tiles = ((m + 63) / 64) * ((ib + 63) / 64);     // 64x64 output tiles of Wk (m x ib)
-        int want = (bt_fill * c.n_cu + tiles - 1) / tiles;  // splits that fill the chip once
+        int want = (2 * c.n_cu + tiles - 1) / tiles;        // splits that fill the resident workgroups once
+        if (want < 1) want = 1;
         int kchunk = (mi + want - 1) / want;
-        if (kchunk < bt_kmin) kchunk = bt_kmin;
+        if (kchunk < 128) kchunk = 128;
         gemm_splitk<T>(c, st, m, ib, mi, Tr<T>::one(), Ca, Vb, Tr<T>::zero(), Wk, m, kchunk);
         // Wk2 = Wk T^H                                (:197-198)
         Operand<T> Tt = op_plain(Tb, ldt, 0, 1);
@@ -193,12 +228,20 @@ static double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// EIGSOLVE_TRACE_MARKS=1: an empty kernel with grid = 1 + 2*phase (+1 at the end of the phase) is launched at every phase
+// boundary, so that a rocprofv3 --kernel-trace of a solve can be segmented exactly (tools/trace_phases.py) -- kernel names
+// alone do not say which phase a gemm belongs to.
+__global__ void phase_marker_kernel(int) {}
+static void phase_mark(const Ctx& c, hipStream_t st, int id) {
+    if (c.trace_marks) hipLaunchKernelGGL(phase_marker_kernel, dim3(1 + id), dim3(64), 0, st, id);
+}
+
 struct PhaseTimer {
     Ctx& c;
     hipStream_t st;
     explicit PhaseTimer(Ctx& cc) : c(cc), st(cc.s1) {}
-    void begin(int ph) { (void)hipEventRecord(c.ev[2 * ph], st); }
-    void end(int ph) { (void)hipEventRecord(c.ev[2 * ph + 1], st); }
+    void begin(int ph) { phase_mark(c, st, 2 * ph); (void)hipEventRecord(c.ev[2 * ph], st); }
+    void end(int ph) { (void)hipEventRecord(c.ev[2 * ph + 1], st); phase_mark(c, st, 2 * ph + 1); }
     void collect(int ph) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c.ev[2 * ph], c.ev[2 * ph + 1]) == hipSuccess) c.phase_ms[ph] += ms;
@@ -291,6 +334,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         double t0 = now_ms();
         double* Qd = nullptr;
         int ldq_d = 0;
+        phase_mark(c, st, 2 * PH_STEDC);
         if (stedc_device(c, st, N, w_d, e_d, w_d, &Qd, &ldq_d, il, iu) != 0) {
             printf(" eigsolve error: device tridiagonal eigensolver failed!\n");
             return -1;
@@ -299,6 +343,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m,
                            (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Z, ldz);
         EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        phase_mark(c, st, 2 * PH_STEDC + 1);
         EIG_HIP(hipStreamSynchronize(st));
         c.phase_ms[PH_STEDC] += now_ms() - t0;
     } else {
@@ -787,6 +832,31 @@ int eigsolve_dgemm_bench(char ta, char tb, int M, int N, int K, const double* A_
     return gemm_bench_entry<double>(ta, tb, M, N, K, A_d, lda, B_d, ldb, C_d, ldc, reps, ms_avg);
 }
 
+// experiment hook (tools/gemm_shapes.py): like ?gemm_bench with beta = 1 and/or operand masks (enum Mask, stored coordinates)
+template <class T>
+static int gemm_probe_entry(char ta, char tb, int M, int N, int K, const T* A, int lda, const T* B, int ldb, T* C, int ldc,
+                            int reps, int beta_one, int maskA, int moffA, int maskB, int moffB, double* ms) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        Operand<T> a = opA(ta, A, lda), b = opB(tb, B, ldb);
+        a.mask = maskA; a.moff = moffA; b.mask = maskB; b.moff = moffB;
+        return bench_loop<T>(c, reps, ms, [&]() {
+            gemm<T>(c, c.s1, M, N, K, Tr<T>::one(), a, b, beta_one ? Tr<T>::one() : Tr<T>::zero(), C, ldc);
+        });
+    });
+}
+extern "C" int eigsolve_zgemm_probe(char ta, char tb, int M, int N, int K, const void* A_d, int lda, const void* B_d, int ldb,
+                                    void* C_d, int ldc, int reps, int beta_one, int maskA, int moffA, int maskB, int moffB,
+                                    double* ms_avg) {
+    return gemm_probe_entry<cplx>(ta, tb, M, N, K, (const cplx*)A_d, lda, (const cplx*)B_d, ldb, (cplx*)C_d, ldc, reps, beta_one,
+                                  maskA, moffA, maskB, moffB, ms_avg);
+}
+extern "C" int eigsolve_dgemm_probe(char ta, char tb, int M, int N, int K, const double* A_d, int lda, const double* B_d, int ldb,
+                                    double* C_d, int ldc, int reps, int beta_one, int maskA, int moffA, int maskB, int moffB,
+                                    double* ms_avg) {
+    return gemm_probe_entry<double>(ta, tb, M, N, K, A_d, lda, B_d, ldb, C_d, ldc, reps, beta_one, maskA, moffA, maskB, moffB, ms_avg);
+}
+
 template <class T> static int her2k_entry(int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc, int reps, double* ms) {
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
@@ -865,10 +935,9 @@ template <class T> static int larft_entry(int N, const T* A, int lda, const T* t
         Ctx& c = ctx();
         const int k = N - 1;
         if (k <= 0) return 0;
-        if (nb2 != 64) nb2 = 128;
         bt_build_T<T>(c, c.s1, N, A, lda, tau, nb2);
-        const int nb = nb2 > N ? N : nb2;
-        const int nblk = (k + nb - 1) / nb, ldt = nb > 64 ? 128 : 64;
+        const int nb = bt_norm_nb(nb2, N);
+        const int nblk = (k + nb - 1) / nb, ldt = nb;
         if (ldt_out < ldt) return -1;
         const T* Tall = c.scratch<T>("bt_T", 0);
         for (int b = 0; b < nblk; ++b)
@@ -887,7 +956,6 @@ int eigsolve_dlarft(int N, const double* A_d, int lda, const double* tau_d, int 
 template <class T> static int unmtr_entry(int N, int m, const T* A, int lda, const T* tau, T* Z, int ldz, int nb2) {
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
-        if (nb2 != 64) nb2 = 128;
         bt_build_T<T>(c, c.s1, N, A, lda, tau, nb2);
         bt_apply<T>(c, c.s1, N, m, A, lda, Z, ldz, nb2);
         EIG_HIP(hipStreamSynchronize(c.s1));

@@ -630,7 +630,7 @@ def test_algorithm_options_agree(env, cplx):
     res = {}
     try:
         for key, opts in (("default", {}), ("gst0", {"gst": 0}), ("gst1", {"gst": 1}), ("gst2", {"gst": 2, "gst_thr": 256}),
-                          ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128}), ("tb64", {"trsm_base": 64}),
+                          ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128}), ("bt512", {"bt_nb": 512}), ("tb64", {"trsm_base": 64}),
                           ("tb256_gst2", {"trsm_base": 256, "gst": 2, "gst_thr": 256}),
                           ("tb512", {"trsm_base": 512}), ("tb1024_gst2", {"trsm_base": 1024, "gst": 2, "gst_thr": 256}),
                           ("potrf_rec", {"potrf": 0})):
@@ -1011,11 +1011,12 @@ def test_c5_batch_through_the_sharding_module(env):
 # stage level: what round 1 only tested end to end
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("n", [65, 129, 300])
-@pytest.mark.parametrize("nb", [64, 128])
+@pytest.mark.parametrize("n", [65, 129, 300, 600])
+@pytest.mark.parametrize("nb", [64, 128, 256, 512])
 def test_larft_and_backtransform_vs_oracle(env, cplx, n, nb):
-    """zlarft_gpu (+ finish_T_block_kernel; merge_T_kernel for nb=128) and the zlarfb_gpu loop (zheevd_gpu.F90:113-213)
-    against the oracle's larft / larfb on the reflectors of an oracle tridiagonalization."""
+    """zlarft_gpu (+ finish_T_block_kernel; merge_T_kernel for nb >= 128, the batched MFMA merges for nb = 256 / 512) and
+    the zlarfb_gpu loop (zheevd_gpu.F90:113-213) against the oracle's larft / larfb on the reflectors of an oracle
+    tridiagonalization."""
     torch, oracle, api = env
     A = oracle.gen_spd(n, 7100 + n, cplx, shift=float(n)) if n < 200 else oracle.gen_spd_fast(n, 7100 + n, cplx, shift=float(n))
     Ao, d, e, tau = oracle.hetrd(np.triu(A), nb=32)
@@ -1023,7 +1024,7 @@ def test_larft_and_backtransform_vs_oracle(env, cplx, n, nb):
     Ad = api.to_device(Ao)
     taud = torch.from_numpy(np.ascontiguousarray(tau)).cuda()
     T = api.larft(Ad, taud, nb)
-    nbe = min(nb, n)
+    nbe = api.bt_block(nb, n)
     nblk = (k + nbe - 1) // nbe
     assert T.shape[0] == nblk
     rng = np.random.default_rng(n + nb)
