@@ -206,10 +206,12 @@ def hegvdx(A_d, B_d, il, iu, ws=None, skip_host_copy=False):
     return info, ws
 
 
-def hegvdx_batch(pairs, il, iu, wss, skip_host_copy=False):
-    """nprob problems of ONE order and type in one call (eigsolve_zhegvdx_batch / eigsolve_dsygvdx_batch): the
-    tridiagonalizations run in lockstep, per-problem results are bit-identical to `hegvdx`.  pairs = [(A_d, B_d), ...]
-    (overwritten like in the reference), wss = one Workspace per problem.  Returns the list of per-problem info values."""
+def hegvdx_batch(pairs, il, iu, wss, skip_host_copy=False, null_entry=None):
+    """nprob problems of ONE order and type in one call (eigsolve_zhegvdx_batch / eigsolve_dsygvdx_batch): the library keeps
+    `batch_workers` of them in flight on its own worker threads (option 0: lockstep tridiagonalizations on the caller's
+    context); per-problem results are bit-identical to `hegvdx`.  pairs = [(A_d, B_d), ...] (overwritten like in the
+    reference), wss = one Workspace per problem.  Returns the list of per-problem info values.  null_entry (tests): name of
+    a pointer array whose second entry is passed as NULL."""
     import torch
     _sync()
     nprob = len(pairs)
@@ -223,6 +225,10 @@ def hegvdx_batch(pairs, il, iu, wss, skip_host_copy=False):
     A, B = arr([p[0] for p in pairs]), arr([p[1] for p in pairs])
     Z, w, work = arr([ws.Z for ws in wss[:nprob]]), arr([ws.w for ws in wss[:nprob]]), arr([ws.work for ws in wss[:nprob]])
     Zh, wh = arr([ws.Z_h for ws in wss[:nprob]]), arr([ws.w_h for ws in wss[:nprob]])
+    if null_entry == "Z_h":
+        Zh[1] = None
+    elif null_entry == "w_h":
+        wh[1] = None
     info = (c_int * nprob)()
     ws0 = wss[0]
     if cx:

@@ -588,7 +588,7 @@ static bool g_use_fast = getenv("EIGSOLVE_GEMM_GENERIC") == nullptr;
 
 // Split-K partial sums live in a per-stream scratch slot: with the two-stream overlap options gemms on c.s1 and c.s2
 // may both take the split path at the same time.
-static const char* splitk_slot(const Ctx& c, hipStream_t st) { return st == c.s2 ? "splitk_s2" : "splitk"; }
+static const char* splitk_slot(const Ctx& c, hipStream_t st) { return (c.s2 && st == c.s2) ? "splitk_s2" : "splitk"; }
 
 template <class T, int BM, int BN>
 static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits) {
@@ -1077,8 +1077,15 @@ __global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int l
     }
     if (!has_p) {
         if (tid == 0) {
-            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0)
+            // Bounded: the other workgroups of this grid have nothing to wait for, so they announce themselves as soon as they
+            // are dispatched -- but if the environment serialises workgroup dispatch (one-CU HSA_CU_MASK, a debugger), this
+            // workgroup must not spin forever: after ~0.1 s it gives up and flags the factorization as failed (info = -4096 - k0,
+            // reported like a bad pivot) instead of hanging the queue; option "potrf" = 0 has no intra-grid dependency.
+            long spins = 0;
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
                 __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1L << 22)) { atomicCAS(info, 0, -4096 - k0); break; }
+            }
         }
         __syncthreads();
     }
@@ -1425,11 +1432,11 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
-    EIG_HIP(hipMemsetAsync(c.d_info, 0, 2 * sizeof(int), st));
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, 4 * sizeof(int), st));
     if (c.potrf_mode == 0) {
         potrf_rec(c, st, N, N, 0, B, ldb, invU);
     } else {
-        unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 1;   // zeroed with d_info above
+        unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 2;   // its own word (d_info[1] is stedc's), zeroed above
         unsigned expect = 0;
         for (int k0 = 0; k0 < N; k0 += DB) {
             const int nb = min(DB, N - k0), rem = N - k0 - nb;
@@ -1640,7 +1647,7 @@ template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A
 }
 
 template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
-    hipStream_t s1 = c.s1, s2 = c.s2;
+    hipStream_t s1 = c.s1, s2 = c.second_stream();
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
     EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), s1));

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -121,8 +122,11 @@ constexpr int kHemvBlocksMax = 8192;
 
 struct Ctx {
     int dev = -1;
-    hipStream_t s1 = nullptr;  // compute stream
-    hipStream_t s2 = nullptr;  // copy / overlap stream
+    hipStream_t s1 = nullptr;  // compute stream: LEASED from the library's stream pool for the duration of an API call
+                               // (StreamLease, context.cpp); wait with sync(), never hipStreamSynchronize
+    int lease_depth = 0;
+    hipStream_t s2 = nullptr;  // private overlap stream, created on first use (second_stream(); "overlap" options only)
+    hipEvent_t evSync = nullptr;
     hipEvent_t ev[2 * PH_COUNT] = {};
     hipEvent_t evA = nullptr, evB = nullptr;
     std::map<std::string, std::pair<void*, size_t>> slots;  // named grow-only device scratch
@@ -154,6 +158,8 @@ struct Ctx {
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
+    int batch_workers = 3;   // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
+                             // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip)
     int trace_marks = 0;     // EIGSOLVE_TRACE_MARKS=1: marker kernels at the phase boundaries (profiling aid, see evd.hip)
 
     template <class T> T* scratch(const char* name, size_t count) {
@@ -162,10 +168,32 @@ struct Ctx {
     void* scratch_bytes(const char* name, size_t bytes);
     void* host_scratch_bytes(const char* name, size_t bytes);
     void release();
+    // Wait until everything THIS context has enqueued on `st` so far is done.  On a shared stream a
+    // hipStreamSynchronize would also wait for whatever the other contexts enqueue meanwhile.
+    void sync(hipStream_t st);
+    void sync() { sync(s1); }
+    hipStream_t second_stream();
     void drop_graphs();   // forget captured launch sequences (an option they bake in has changed)
 };
 
 Ctx& ctx();  // lazily created for the current device + calling thread
+
+// Every public entry point holds one of these while it runs: the context's compute stream comes from a process-wide pool and
+// goes back when the call returns (after a sync), so the library never owns more streams than it has calls in flight.
+struct StreamLease {
+    Ctx& c;
+    explicit StreamLease(Ctx& ctx_);
+    ~StreamLease();
+    StreamLease(const StreamLease&) = delete;
+    StreamLease& operator=(const StreamLease&) = delete;
+};
+void copy_options(Ctx& dst, const Ctx& src);   // all tunables of src (eigsolve_set_option / environment) into dst
+
+// The library's own worker threads (context.cpp): runs fn(0) ... fn(ntasks-1) on `nworkers` of them, device `dev` current,
+// each worker taking the next task as it finishes one; returns when all are done.  A worker keeps its per-thread context
+// (stream, scratch) from call to call.
+void batch_run(int dev, int nworkers, int ntasks, const std::function<void(int)>& fn);
+void batch_workers_finalize(int dev);          // every worker releases its context for `dev`
 
 // host LAPACK plumbing (context.cpp)
 stedc_fn get_dstedc();

@@ -3,7 +3,11 @@
 // (lib_eigsolve/toolbox.F90:25-99) of the reference.
 #include <dlfcn.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 
 #include "../../include/eigsolve_gpu.h"
 #include "common.h"
@@ -27,6 +31,39 @@ struct CtxHolder {
     }
 };
 thread_local CtxHolder t_ctx;
+
+// Stream pool.  Every hipStream occupies one of the process' few hardware queues (GPU_MAX_HW_QUEUES, default 4, one of them
+// taken by the null stream) and what a batch of solves achieves depends on how its launch chains are spread over them:
+// measured at C3 with three solves in flight, 16.0 problems/s when every chain has a hardware queue of its own, 12.4-12.8
+// when two of them share one (profiles/r03_experiments.txt; which queue a new stream gets once all are taken is the
+// runtime's choice -- rocprofv3 showed the 4th library stream landing on an already busy queue or on the idle null
+// stream's, depending on creation order).  The library therefore keeps its stream count at the number of API calls that
+// are actually in flight: a context has no stream of its own; every public entry point leases one from this pool for the
+// duration of the call (StreamLease) and gives it back, synchronised, on return.  A single-threaded caller uses one
+// stream for ever, a batch with three problems in flight three, however many threads have ever called the library.
+struct PooledStream {
+    hipStream_t s;
+    bool busy;
+};
+std::mutex g_stream_mu;
+std::map<int, std::vector<PooledStream>> g_streams;   // per device
+hipStream_t lease_stream(int dev, hipStream_t prefer) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& v = g_streams[dev];
+    for (auto& p : v)
+        if (!p.busy && p.s == prefer) { p.busy = true; return p.s; }
+    for (auto& p : v)
+        if (!p.busy) { p.busy = true; return p.s; }
+    hipStream_t s = nullptr;
+    EIG_HIP(hipStreamCreate(&s));   // blocking streams, like the reference's cudaStreamCreate (eigsolve_vars.F90:50-52)
+    v.push_back(PooledStream{s, true});
+    return s;
+}
+void return_stream(int dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (auto& p : g_streams[dev])
+        if (p.s == s) p.busy = false;
+}
 
 std::mutex g_lapack_mu;
 void* g_lapack_handle = nullptr;
@@ -60,8 +97,8 @@ void* Ctx::scratch_bytes(const char* name, size_t bytes) {
     auto& s = slots[name];
     if (s.second < bytes) {
         if (s.first) {
-            EIG_HIP(hipStreamSynchronize(s1));
-            EIG_HIP(hipStreamSynchronize(s2));
+            if (lease_depth > 0) sync(s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
+            if (s2) EIG_HIP(hipStreamSynchronize(s2));
             EIG_HIP(hipFree(s.first));
         }
         size_t cap = bytes + bytes / 8 + 256;
@@ -82,9 +119,31 @@ void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
     return s.first;
 }
 
+StreamLease::StreamLease(Ctx& ctx_) : c(ctx_) {
+    if (c.lease_depth++ == 0) c.s1 = lease_stream(c.dev, c.s1);
+}
+StreamLease::~StreamLease() {
+    if (--c.lease_depth == 0 && c.s1) {
+        // nothing of this call may still be running on the stream when another context takes it (an exception may have
+        // cut the call short of its final sync)
+        if (c.evSync && hipEventRecord(c.evSync, c.s1) == hipSuccess) (void)hipEventSynchronize(c.evSync);
+        return_stream(c.dev, c.s1);
+    }
+}
+
+void Ctx::sync(hipStream_t st) {
+    if (st == s2 && s2) { EIG_HIP(hipStreamSynchronize(s2)); return; }
+    EIG_HIP(hipEventRecord(evSync, st));
+    EIG_HIP(hipEventSynchronize(evSync));
+}
+
+hipStream_t Ctx::second_stream() {
+    if (!s2) EIG_HIP(hipStreamCreate(&s2));
+    return s2;
+}
+
 void Ctx::drop_graphs() {
     if (graphs.empty()) return;
-    if (s1) (void)hipStreamSynchronize(s1);
     for (auto& kv : graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -96,7 +155,6 @@ void Ctx::release() {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return;   // runtime already gone (process teardown): nothing to free
     if (dev >= 0 && cur != dev) (void)hipSetDevice(dev);
-    if (s1) (void)hipStreamSynchronize(s1);
     if (s2) (void)hipStreamSynchronize(s2);
     drop_graphs();
     for (auto& kv : slots)
@@ -111,11 +169,121 @@ void Ctx::release() {
     if (evB) (void)hipEventDestroy(evB);
     if (d_info) (void)hipFree(d_info);
     if (h_info) (void)hipHostFree(h_info);
-    if (s1) (void)hipStreamDestroy(s1);
+    if (evSync) (void)hipEventDestroy(evSync);
+    evSync = nullptr;
+    // s1 belongs to the stream pool: never destroyed
     if (s2) (void)hipStreamDestroy(s2);
     for (auto& e : ev) e = nullptr;
     evA = evB = nullptr; d_info = nullptr; h_info = nullptr; s1 = s2 = nullptr;
     if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);
+}
+
+void copy_options(Ctx& c, const Ctx& d) {
+    c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
+    c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
+    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
+    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks;
+}
+
+// ---- the library's worker threads ------------------------------------------------------------------------------------
+// eigsolve_?hegvdx_batch keeps several problems in flight on ONE caller thread by handing them to these threads (QE's k-point
+// loop is a single-threaded Fortran caller; SURVEY.md 8(b) "Threading").  The threads are created on first use, never
+// joined (they idle on a condition variable; the process exit ends them) and own ordinary per-thread contexts.
+namespace {
+struct WorkerPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    int nthreads = 0;
+    void ensure(int n) {   // mu held
+        while (nthreads < n) {
+            std::thread([this] {
+                for (;;) {
+                    std::function<void()> f;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !q.empty(); });
+                        f = std::move(q.front());
+                        q.pop_front();
+                    }
+                    f();
+                }
+            }).detach();
+            ++nthreads;
+        }
+    }
+};
+WorkerPool& workers() {
+    static WorkerPool* p = new WorkerPool();   // leaked on purpose: no destructor may run while a worker still waits on it
+    return *p;
+}
+}  // namespace
+
+void batch_run(int dev, int nworkers, int ntasks, const std::function<void(int)>& fn) {
+    if (ntasks <= 0) return;
+    if (nworkers > ntasks) nworkers = ntasks;
+    if (nworkers < 1) nworkers = 1;
+    struct Call {
+        std::atomic<int> next{0};
+        std::mutex mu;
+        std::condition_variable cv;
+        int running = 0;
+    } call;
+    auto loop = [&call, &fn, ntasks] {
+        for (int t; (t = call.next.fetch_add(1)) < ntasks;) {
+            try { fn(t); } catch (...) { }   // fn reports through its own info slot
+        }
+    };
+    // The CALLER is one of the workers (it would only wait otherwise): a batch with w problems in flight then uses w streams
+    // in all -- the caller's context and w - 1 pool threads' -- and w = 3 fits the 4 hardware queues ROCm gives a process by
+    // default next to the null stream.  (With the caller idle and 3 pool threads, i.e. 4 library streams, two of the three
+    // active launch chains ended up sharing a hardware queue: 12.8 instead of 16.0 problems/s at C3.)
+    const int helpers = nworkers - 1;
+    call.running = helpers;
+    if (helpers > 0) {
+        WorkerPool& wp = workers();
+        {
+            std::lock_guard<std::mutex> lk(wp.mu);
+            wp.ensure(helpers);
+            for (int w = 0; w < helpers; ++w)
+                wp.q.emplace_back([&call, &loop, dev] {
+                    (void)hipSetDevice(dev);
+                    loop();
+                    std::lock_guard<std::mutex> lk2(call.mu);
+                    if (--call.running == 0) call.cv.notify_all();
+                });
+        }
+        wp.cv.notify_all();
+    }
+    loop();
+    std::unique_lock<std::mutex> lk(call.mu);
+    call.cv.wait(lk, [&] { return call.running == 0; });
+}
+
+void batch_workers_finalize(int dev) {
+    int n;
+    {
+        std::lock_guard<std::mutex> lk(workers().mu);
+        n = workers().nthreads;
+    }
+    if (n == 0) return;
+    // one task per worker thread: a barrier inside makes sure every thread takes exactly one
+    // (the caller takes part in batch_run as a worker: n + 1 tasks for n pool threads + the caller, whose own context is
+    //  released by eigsolve_finalize right after)
+    std::atomic<int> arrived{0};
+    const std::thread::id me = std::this_thread::get_id();
+    batch_run(dev, n + 1, n + 1, [&](int) {
+        if (std::this_thread::get_id() != me) {
+            auto it = t_ctx.m.find(dev);
+            if (it != t_ctx.m.end()) {
+                it->second->release();
+                delete it->second;
+                t_ctx.m.erase(it);
+            }
+        }
+        arrived.fetch_add(1);
+        while (arrived.load() < n + 1) std::this_thread::yield();
+    });
 }
 
 // tunables: compile-time defaults, overridden by the environment (eigsolve_set_option changes them per context afterwards)
@@ -124,6 +292,9 @@ static void init_options(Ctx& c) {
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
+    c.batch_workers = d.batch_workers;
+    if (const char* e = getenv("EIGSOLVE_BATCH_WORKERS")) c.batch_workers = atoi(e);
+    if (c.batch_workers < 0 || c.batch_workers > 16) c.batch_workers = d.batch_workers;
     if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRACE_MARKS")) c.trace_marks = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
@@ -152,8 +323,8 @@ Ctx& ctx() {
     if (it != t_ctx.m.end()) return *it->second;
     {   // a context a finished thread left behind for this device?
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        for (size_t i = 0; i < g_pool.size(); ++i)
-            if (g_pool[i]->dev == dev) {
+        for (size_t i = g_pool.size(); i-- > 0;)      // most recently returned first: a stream of short-lived threads keeps
+            if (g_pool[i]->dev == dev) {              // re-using ONE warm context instead of cycling through (and growing) all
                 Ctx* c = g_pool[i];
                 g_pool.erase(g_pool.begin() + i);
                 init_options(*c);          // tunables are per owner: back to the defaults / environment
@@ -163,10 +334,8 @@ Ctx& ctx() {
     }
     Ctx* c = new Ctx();
     c->dev = dev;
-    // blocking streams, like the reference's cudaStreamCreate (eigsolve_vars.F90:50-52)
-    EIG_HIP(hipStreamCreate(&c->s1));
-    EIG_HIP(hipStreamCreate(&c->s2));
     for (auto& e : c->ev) EIG_HIP(hipEventCreate(&e));
+    EIG_HIP(hipEventCreateWithFlags(&c->evSync, hipEventDisableTiming));
     EIG_HIP(hipEventCreateWithFlags(&c->evA, hipEventDisableTiming));
     EIG_HIP(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming));
     EIG_HIP(hipMalloc((void**)&c->d_info, 64));
@@ -272,6 +441,7 @@ int eigsolve_init(void) {
 int eigsolve_finalize(void) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
+    eig::batch_workers_finalize(dev);
     {   // contexts finished threads left behind for this device
         std::lock_guard<std::mutex> lk(eig::g_pool_mu);
         for (size_t i = 0; i < eig::g_pool.size();) {
@@ -318,6 +488,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
         else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? eig::kGstModeDefault : value;
         else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
+        else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? 3 : value;
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

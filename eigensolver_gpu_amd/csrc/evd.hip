@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <initializer_list>
 
 #include "../../include/eigsolve_gpu.h"
 #include "stedc.h"
@@ -260,11 +261,12 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     // The real reference path copies the eigenvectors from column 1 whatever il is (dsyevd_gpu.F90:108; the complex path
     // honours il, zheevd_gpu.F90:110).  Default: honour il in both; option "real_il_reference" = 1 reproduces the quirk.
     if (!Tr<T>::cx && c.real_il_reference) { iu = iu - il + 1; il = 1; }
-    phase_range_push(Tr<T>::cx ? "zhetrd" : "dsytrd");   // zheevd_gpu.F90:80
-    pt.begin(PH_TRD);
     const T* Vsrc = A;      // where the reflectors live for the back-transformation
     int ldv = lda;
     const T* tau_bt = tau_d;
+    {
+    PhaseRange trd_range(Tr<T>::cx ? "zhetrd" : "dsytrd");   // zheevd_gpu.F90:80
+    pt.begin(PH_TRD);
     if (c.use_graph && N > 64) {
         // hipGraph path: fixed-address internal working set, launch sequence captured once per (type, N).
         const size_t NN = (size_t)N * N;
@@ -277,14 +279,14 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         (void)hemv_scratch_touch<T>(c, N, cur + 5);   // all scratch used inside the captured region exists before capture
         cur[0] = Aw; cur[1] = Ww; cur[2] = tauw; cur[3] = dw; cur[4] = ew;
         char key[64];
-        snprintf(key, sizeof key, "trd_%c_%d_%d_%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks);
+        snprintf(key, sizeof key, "trd_%c_%d_%d_%d_%d%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks, c.p_wt, c.hemv_balance);
         Ctx::GraphEntry& ge = c.graphs[key];
         bool valid = ge.exec != nullptr;
         for (int q = 0; q < 16 && valid; ++q) valid = (ge.ptrs[q] == cur[q]);
         if (!valid) {
             if (ge.exec) { (void)hipGraphExecDestroy(ge.exec); ge.exec = nullptr; }
             if (ge.graph) { (void)hipGraphDestroy(ge.graph); ge.graph = nullptr; }
-            EIG_HIP(hipStreamSynchronize(st));
+            c.sync(st);
             EIG_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             try {
                 hetrd_upper<T>(c, st, N, Aw, N, dw, ew, tauw, Ww, c.trd_nb);
@@ -314,11 +316,11 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
     }
     pt.end(PH_TRD);
-    phase_range_pop();
+    }
     // larft T factors depend only on the reflectors: build them on the second stream while the tridiagonal
     // eigenproblem is being solved (zheevd_gpu.F90:125 does the same per block with stream1/stream2)
     const bool ovT = (c.overlap & 2) != 0;
-    hipStream_t stT = ovT ? c.s2 : st;
+    hipStream_t stT = ovT ? c.second_stream() : st;
     if (ovT) {
         EIG_HIP(hipEventRecord(c.evA, st));
         EIG_HIP(hipStreamWaitEvent(stT, c.evA, 0));
@@ -329,7 +331,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     PhaseRange stedc_range(Tr<T>::cx ? "zstedc" : "dstedc");   // zheevd_gpu.F90:100
     if (c.tridiag_device) {
         // device-side divide & conquer: no N x N host round trip at all
-        EIG_HIP(hipStreamSynchronize(st));
+        c.sync(st);
         pt.collect(PH_TRD);
         double t0 = now_ms();
         double* Qd = nullptr;
@@ -344,13 +346,13 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
                            (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Z, ldz);
         EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
         phase_mark(c, st, 2 * PH_STEDC + 1);
-        EIG_HIP(hipStreamSynchronize(st));
+        c.sync(st);
         c.phase_ms[PH_STEDC] += now_ms() - t0;
     } else {
     // d, e -> host (zheevd_gpu.F90:85-86)
     EIG_HIP(hipMemcpyAsync(w_h, w_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     if (N > 1) EIG_HIP(hipMemcpyAsync(e_h, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     pt.collect(PH_TRD);
     double t0 = now_ms();
     stedc_fn f = get_dstedc();
@@ -373,7 +375,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     size_t tot = (size_t)N * m;
     hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m, (const double*)Qd, N, Z,
                        ldz);
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     c.phase_ms[PH_STEDC] += now_ms() - t0;
     }
     }
@@ -407,7 +409,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
         potrf_hegst_overlapped<T>(c, N, A, lda, B, ldb);
         pt.end(PH_POTRF);
         EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-        EIG_HIP(hipStreamSynchronize(st));
+        c.sync(st);
         pt.collect(PH_POTRF);
         if (c.h_info[0] != 0) {
             printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
@@ -418,25 +420,28 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
         pt.end(PH_GST);
     } else {
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
-    phase_range_push(Tr<T>::cx ? "cusolverdnZpotrf" : "cusolverdnDpotrf");   // the reference's range name, :134
-    pt.begin(PH_POTRF);
-    potrf_upper<T>(c, st, N, B, ldb);
-    pt.end(PH_POTRF);
-    phase_range_pop();
+    {
+        PhaseRange r(Tr<T>::cx ? "cusolverdnZpotrf" : "cusolverdnDpotrf");   // the reference's range name, :134
+        pt.begin(PH_POTRF);
+        potrf_upper<T>(c, st, N, B, ldb);
+        pt.end(PH_POTRF);
+    }
     EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     pt.collect(PH_POTRF);
     if (c.h_info[0] != 0) {
-        printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
+        if (c.h_info[0] < 0) printf(" %s error: potrf failed! (the block-row kernel could not synchronise its workgroups; use option potrf = 0)\n", name);
+        else printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
         return -1;
     }
     // The reference saves strict-lower(A) in Z here and restores it later (:144-152) because
     // its gst/td2 overwrite parts of it; this implementation never writes below the diagonal.
-    phase_range_push(Tr<T>::cx ? "zhegst_gpu" : "dsygst_gpu");   // :155
-    pt.begin(PH_GST);   // (potrf_upper has merged the inverse diagonal blocks already)
-    hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
-    pt.end(PH_GST);
-    phase_range_pop();
+    {
+        PhaseRange r(Tr<T>::cx ? "zhegst_gpu" : "dsygst_gpu");   // :155
+        pt.begin(PH_GST);   // (potrf_upper has merged the inverse diagonal blocks already)
+        hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
+        pt.end(PH_GST);
+    }
     }
     int info;
     {
@@ -445,11 +450,12 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
                              liwork);  // :163
     }
     if (info != 0) return -1;
-    phase_range_push(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167
-    pt.begin(PH_TRSM);
-    trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz, c.trsm_base);  // :169
-    pt.end(PH_TRSM);
-    phase_range_pop();
+    {
+        PhaseRange r(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167
+        pt.begin(PH_TRSM);
+        trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz, c.trsm_base);  // :169
+        pt.end(PH_TRSM);
+    }
     pt.begin(PH_D2H);
     if (!skip_host_copy) {
         hipError_t e = hipMemcpy2DAsync(Z_h, sizeof(T) * ldz_h, Z, sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
@@ -459,7 +465,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
         }
     }
     pt.end(PH_D2H);
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     pt.collect(PH_GST); pt.collect(PH_BT); pt.collect(PH_TRSM); pt.collect(PH_D2H);
     c.phase_ms[PH_TOTAL] = now_ms() - t_all;
     return 0;
@@ -479,6 +485,7 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
     clear_phases(c);
     const double t_all = now_ms();
     const int m = iu - il + 1;
+    if (!Tr<T>::cx && c.real_il_reference) { iu = iu - il + 1; il = 1; }   // as heevd_core (dsyevd_gpu.F90:108)
     int* h_inf = reinterpret_cast<int*>(c.host_scratch_bytes("batch_info", sizeof(int) * (size_t)nprob));
     {
         PhaseRange r("batch: potrf + hegst");
@@ -492,7 +499,7 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
         PhaseRange r(Tr<T>::cx ? "batch: zhetrd lockstep" : "batch: dsytrd lockstep");
         hetrd_upper_batch<T>(c, st, N, nprob, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
     }
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     int bad = 0;
     for (int q = 0; q < nprob; ++q) {
         infos[q] = 0;
@@ -537,14 +544,53 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
             }
         }
     }
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     c.phase_ms[PH_TOTAL] = now_ms() - t_all;
     return bad ? -1 : 0;
+}
+
+template <class F> static int guarded(int* info, F&& f);
+
+// ---- batch of problems on the library's worker threads ----------------------------------------------------------------
+// One call, one caller thread, `c0.batch_workers` problems in flight: every problem is an ordinary single-problem solve
+// (hegvdx_core) on a worker thread's own context and stream, so per-problem results are bit-identical to the one-problem
+// driver's and the latency-bound phases of one solve (the Cholesky chain, the per-column kernels of the tridiagonalization,
+// the divide & conquer tree) fill under the kernels of the others -- what a caller otherwise needs a host thread per
+// problem for (bench.py --inflight).  The reference solves one problem per call (zhegvdx_gpu.F90:75).
+template <class T>
+static int hegvdx_batch_workers(Ctx& c0, int nprob, int N, T* const* A, int lda, T* const* B, int ldb, T* const* Z, int ldz, int il,
+                                int iu, double* const* w_d, double* const* e_d, T* const* tau_d, T* const* W_d, double* const* w_h,
+                                T* const* Z_h, int ldz_h, int skip_host_copy, int* infos, const char* name) {
+    clear_phases(c0);
+    const double t_all = now_ms();
+    batch_run(c0.dev, c0.batch_workers, nprob, [&](int q) {
+        guarded(&infos[q], [&]() -> int {
+            Ctx& c = ctx();
+            copy_options(c, c0);
+            return hegvdx_core<T>(c, N, A[q], lda, B[q], ldb, Z[q], ldz, il, iu, w_d[q], e_d[q], tau_d[q], W_d[q], w_h[q], nullptr,
+                                  nullptr, N, nullptr, 0, nullptr, 0, Z_h ? Z_h[q] : nullptr, ldz_h, skip_host_copy, name);
+        });
+    });
+    int bad = 0;
+    for (int q = 0; q < nprob; ++q) bad |= (infos[q] != 0);
+    c0.phase_ms[PH_TOTAL] = now_ms() - t_all;
+    return bad ? -1 : 0;
+}
+
+// the batch ABI hands over arrays of pointers: none of them, and none of their entries, may be null
+static bool batch_ptrs_ok(int nprob, std::initializer_list<const void* const*> arrays) {
+    for (const void* const* a : arrays) {
+        if (!a) return false;
+        for (int q = 0; q < nprob; ++q)
+            if (!a[q]) return false;
+    }
+    return true;
 }
 
 template <class F> static int guarded(int* info, F&& f) {
     int r;
     try {
+        StreamLease lease(ctx());   // the context's compute stream for this call (nested calls share it)
         r = f();
     } catch (const HipFail&) {
         r = -1;
@@ -558,11 +604,11 @@ template <class F> static int guarded(int* info, F&& f) {
 template <class T> static int bench_loop(Ctx& c, int reps, double* ms_avg, const std::function<void()>& body) {
     if (reps < 1) reps = 1;
     body();  // warm-up
-    EIG_HIP(hipStreamSynchronize(c.s1));
+    c.sync(c.s1);
     EIG_HIP(hipEventRecord(c.ev[0], c.s1));
     for (int r = 0; r < reps; ++r) body();
     EIG_HIP(hipEventRecord(c.ev[1], c.s1));
-    EIG_HIP(hipStreamSynchronize(c.s1));
+    c.sync(c.s1);
     float ms = 0.f;
     EIG_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     if (ms_avg) *ms_avg = (double)ms / reps;
@@ -640,6 +686,13 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
         if (lwork < 2 * 64 * 64 + 65 * n) { printf(" zhegvdx_gpu error: lwork must be at least 2*64*64 + 65*N\n"); return -1; }
         if (lrwork < n) { printf(" zhegvdx_gpu error: lrwork must be at least N\n"); return -1; }
         if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" zhegvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        if (!batch_ptrs_ok(nprob, {(const void* const*)A_d, (const void* const*)B_d, (const void* const*)Z_d, (const void* const*)w_d,
+                                   (const void* const*)work_d, (const void* const*)rwork_d, (const void* const*)w_h}) ||
+            (!skip_host_copy && !batch_ptrs_ok(nprob, {(const void* const*)Z_h}))) {
+            printf(" zhegvdx_gpu batch error: null pointer in the argument arrays\n");
+            for (int q = 0; q < nprob; ++q) info[q] = -1;
+            return -1;
+        }
         Ctx& c = ctx();
         if (!c.tridiag_device) { printf(" zhegvdx_gpu batch error: the batch driver needs the device tridiagonal solver (tridiag = 1)\n"); return -1; }
         std::vector<cplx*> A(nprob), B(nprob), Z(nprob), tau(nprob), W(nprob), Zh(nprob);
@@ -648,6 +701,9 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
             A[q] = (cplx*)A_d[q]; B[q] = (cplx*)B_d[q]; Z[q] = (cplx*)Z_d[q]; Zh[q] = Z_h ? (cplx*)Z_h[q] : nullptr;
             tau[q] = (cplx*)work_d[q]; W[q] = (cplx*)work_d[q] + n; e[q] = rwork_d[q];       // carve-up of zheevd_gpu.F90:68-75
         }
+        if (c.batch_workers > 0)
+            return hegvdx_batch_workers<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
+                                              W.data(), w_h, Z_h ? Zh.data() : nullptr, ldz_h, skip_host_copy, info, "zhegvdx_gpu");
         return hegvdx_batch_core<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
                                        W.data(), w_h, Zh.data(), ldz_h, skip_host_copy, info, "zhegvdx_gpu");
     });
@@ -662,10 +718,20 @@ int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double
         if (nprob < 1 || nprob > 64 || !info) { printf(" dsygvdx_gpu batch error: nprob must be in 1..64 and info an array of nprob ints\n"); return -1; }
         if (lwork < 2 * 64 * 64 + 66 * n) { printf(" dsygvdx_gpu error: lwork must be at least 2*64*64 + 66*N\n"); return -1; }
         if (N <= 0 || il < 1 || iu > N || iu < il) { printf(" dsygvdx_gpu error: invalid N/il/iu\n"); return -1; }
+        if (!batch_ptrs_ok(nprob, {(const void* const*)A_d, (const void* const*)B_d, (const void* const*)Z_d, (const void* const*)w_d,
+                                   (const void* const*)work_d, (const void* const*)w_h}) ||
+            (!skip_host_copy && !batch_ptrs_ok(nprob, {(const void* const*)Z_h}))) {
+            printf(" dsygvdx_gpu batch error: null pointer in the argument arrays\n");
+            for (int q = 0; q < nprob; ++q) info[q] = -1;
+            return -1;
+        }
         Ctx& c = ctx();
         if (!c.tridiag_device) { printf(" dsygvdx_gpu batch error: the batch driver needs the device tridiagonal solver (tridiag = 1)\n"); return -1; }
         std::vector<double*> e(nprob), tau(nprob), W(nprob);
         for (int q = 0; q < nprob; ++q) { e[q] = work_d[q]; tau[q] = work_d[q] + n; W[q] = work_d[q] + 2 * n; }   // dsyevd_gpu.F90:68-74
+        if (c.batch_workers > 0)
+            return hegvdx_batch_workers<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h,
+                                                Z_h, ldz_h, skip_host_copy, info, "dsygvdx_gpu");
         return hegvdx_batch_core<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h, Z_h,
                                          ldz_h, skip_host_copy, info, "dsygvdx_gpu");
     });
@@ -687,7 +753,7 @@ int eigsolve_zheevd(int il, int iu, int N, void* A_d, int lda, void* Z_d, int ld
         cplx* work = (cplx*)work_d;
         int r = heevd_core<cplx>(c, il, iu, N, (cplx*)A_d, lda, (cplx*)Z_d, ldz, w_d, rwork_d, work, work + n, w_h, rwork_h,
                                  rwork_h + n, N, rwork_h + n + n * n, (long)lrwork_h - n - n * n, iwork_h, liwork_h);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return r;
     });
 }
@@ -706,7 +772,7 @@ int eigsolve_dsyevd(int il, int iu, int N, double* A_d, int lda, double* Z_d, in
         clear_phases(c);
         int r = heevd_core<double>(c, il, iu, N, A_d, lda, Z_d, ldz, w_d, work_d, work_d + n, work_d + 2 * n, w_h, work_h,
                                    work_h + 2 * n, N, work_h + 2 * n + n * n, (long)lwork_h - 2 * n - n * n, iwork_h, liwork_h);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return r;
     });
 }
@@ -718,7 +784,7 @@ int eigsolve_zhegst(int N, void* A_d, int lda, const void* B_d, int ldb, int nb)
         build_invU<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
         build_inv_blocks<cplx>(c, c.s1, N, (const cplx*)B_d, ldb);
         hegst_upper<cplx>(c, c.s1, N, (cplx*)A_d, lda, (const cplx*)B_d, ldb);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -729,7 +795,7 @@ int eigsolve_dsygst(int N, double* A_d, int lda, const double* B_d, int ldb, int
         build_invU<double>(c, c.s1, N, B_d, ldb);
         build_inv_blocks<double>(c, c.s1, N, B_d, ldb);
         hegst_upper<double>(c, c.s1, N, A_d, lda, B_d, ldb);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -742,7 +808,7 @@ template <class T> static int hetrd_entry(int N, T* A, int lda, double* d, doubl
         T* W = work;
         if (!W || (long)lwork < (long)N * nb) W = c.scratch<T>("trd_W", (size_t)N * nb);
         hetrd_upper<T>(c, c.s1, N, A, lda, d, e, tau, W, nb);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -758,7 +824,7 @@ template <class T> static int potrf_entry(int N, T* B, int ldb, int* info_h) {
         Ctx& c = ctx();
         potrf_upper<T>(c, c.s1, N, B, ldb);
         EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, c.s1));
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         if (info_h) *info_h = c.h_info[0];
         return 0;
     });
@@ -770,7 +836,7 @@ template <class T> static int hemv_entry(int n, const T* A, int lda, const T* x,
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         hemv_upper<T>(c, c.s1, n, A, lda, x, y, true);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -801,7 +867,7 @@ static int gemm_entry(char ta, char tb, int M, int N, int K, const double* alpha
     return guarded(nullptr, [&]() -> int {
         Ctx& c = ctx();
         gemm<T>(c, c.s1, M, N, K, scal_from<T>(alpha), opA(ta, A, lda), opB(tb, B, ldb), scal_from<T>(beta), C, ldc);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -862,7 +928,7 @@ template <class T> static int her2k_entry(int n, int k, const T* V, int ldv, con
         Ctx& c = ctx();
         if (reps > 0) return bench_loop<T>(c, reps, ms, [&]() { her2k_un<T>(c, c.s1, n, k, V, ldv, W, ldw, C, ldc); });
         her2k_un<T>(c, c.s1, n, k, V, ldv, W, ldw, C, ldc);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -887,7 +953,7 @@ template <class T> static int trsm_entry(int N, int m, const T* U, int ldu, T* Z
         build_invU<T>(c, c.s1, N, U, ldu);
         build_inv_blocks<T>(c, c.s1, N, U, ldu);
         trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz, c.trsm_base);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -908,12 +974,12 @@ template <class T> static int mv_sweep_entry(int N, T* A, int lda, int nb, int r
         EIG_HIP(hipMemsetAsync(W, 0, sizeof(T) * (size_t)N * 64, c.s1));
         long nl = 0; double by = 0;
         hetrd_mv_sweep<T>(c, c.s1, N, A, lda, W, nb, e, tau, &nl, &by);  // warm-up
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         if (reps < 1) reps = 1;
         EIG_HIP(hipEventRecord(c.ev[0], c.s1));
         for (int r = 0; r < reps; ++r) hetrd_mv_sweep<T>(c, c.s1, N, A, lda, W, nb, e, tau, &nl, &by);
         EIG_HIP(hipEventRecord(c.ev[1], c.s1));
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         float ms = 0.f;
         EIG_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
         if (ms_total) *ms_total = (double)ms / reps;
@@ -943,7 +1009,7 @@ template <class T> static int larft_entry(int N, const T* A, int lda, const T* t
         for (int b = 0; b < nblk; ++b)
             EIG_HIP(hipMemcpy2DAsync(T_out + (size_t)b * ldt_out * ldt_out, sizeof(T) * ldt_out, Tall + (size_t)b * ldt * ldt,
                                      sizeof(T) * ldt, sizeof(T) * ldt, ldt, hipMemcpyDeviceToDevice, c.s1));
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -958,7 +1024,7 @@ template <class T> static int unmtr_entry(int N, int m, const T* A, int lda, con
         Ctx& c = ctx();
         bt_build_T<T>(c, c.s1, N, A, lda, tau, nb2);
         bt_apply<T>(c, c.s1, N, m, A, lda, Z, ldz, nb2);
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         return 0;
     });
 }
@@ -979,7 +1045,7 @@ int eigsolve_dstedc_device(int N, const double* d_d, const double* e_d, double* 
         int r = stedc_device(c, c.s1, N, d_d, e_d, w_d, &Qs, &lds_);
         if (r == 0 && Q_d)
             EIG_HIP(hipMemcpy2DAsync(Q_d, sizeof(double) * ldq, Qs, sizeof(double) * lds_, sizeof(double) * N, N, hipMemcpyDeviceToDevice, c.s1));
-        EIG_HIP(hipStreamSynchronize(c.s1));
+        c.sync(c.s1);
         if (ms) *ms = now_ms() - t0;
         return r;
     });

@@ -447,7 +447,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     std::vector<double> d(N), e(N > 1 ? N - 1 : 1, 0.0);
     EIG_HIP(hipMemcpyAsync(d.data(), d_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     if (N > 1) EIG_HIP(hipMemcpyAsync(e.data(), e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     double orgnrm = 0.0;
     for (int i = 0; i < N; ++i) orgnrm = std::max(orgnrm, std::fabs(d[i]));
     for (int i = 0; i + 1 < N; ++i) orgnrm = std::max(orgnrm, std::fabs(e[i]));
@@ -540,7 +540,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
         for (size_t i = 0; i < leaves.size(); ++i) { lo[i] = nodes[leaves[i]].off; ln[i] = nodes[leaves[i]].n; }
         EIG_HIP(hipMemcpyAsync(d_leafoff, lo.data(), sizeof(int) * lo.size(), hipMemcpyHostToDevice, st));
         EIG_HIP(hipMemcpyAsync(d_leafn, ln.data(), sizeof(int) * ln.size(), hipMemcpyHostToDevice, st));
-        EIG_HIP(hipStreamSynchronize(st));  // lo/ln are stack vectors
+        c.sync(st);  // lo/ln are stack vectors
         hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, (const int*)d_leafoff, (const int*)d_leafn,
                            (const double*)d_dmod, (const double*)d_e, Da, Qa, ldq, d_info);
         EIG_HIP(hipGetLastError());
@@ -599,7 +599,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
                            (const int*)(d_zrow_all + (size_t)level * N), (const double*)(d_zscale_all + (size_t)level * N),
                            (const double*)Dcur, d_z);
         EIG_HIP(hipMemcpyAsync(h_zD, d_z, sizeof(double) * 2 * (size_t)N, hipMemcpyDeviceToHost, st));
-        EIG_HIP(hipStreamSynchronize(st));
+        c.sync(st);
 
         // ---- deflation scan per merge (host, sequential in j; LAPACK dlaed2's logic) ----
         h_md.clear();
@@ -703,7 +703,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
                 // only eigenvectors il..iu are consumed (zheevd_gpu.F90:110): the roots are ascending, so the wanted ones
                 // are a contiguous range [tlo, thi] of the root merge's columns
                 EIG_HIP(hipMemcpyAsync(h_pos, d_posnd, sizeof(int) * h_md[0].k, hipMemcpyDeviceToHost, st));
-                EIG_HIP(hipStreamSynchronize(st));
+                c.sync(st);
                 const int kroot = h_md[0].k;
                 tlo = kroot; thi = -1;
                 for (int q = 0; q < kroot; ++q)
@@ -769,7 +769,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     EIG_HIP(hipMemcpyAsync(w_d, Dcur, sizeof(double) * N, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(dc_scale_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, w_d, orgnrm);
     EIG_HIP(hipMemcpyAsync(c.h_info + 1, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     *Q_out = Qcur;
     *ldq_out = ldq;
     return c.h_info[1] == 0 ? 0 : -1;

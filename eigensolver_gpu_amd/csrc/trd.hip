@@ -798,7 +798,7 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     T one = Tr<T>::one();
     EIG_HIP(hipMemcpyAsync(sc.alphaSlot, &one, sizeof(T), hipMemcpyHostToDevice, st));
     EIG_HIP(hipMemcpyAsync(sc.xbuf, A, sizeof(T) * N, hipMemcpyDeviceToDevice, st));
-    EIG_HIP(hipStreamSynchronize(st));
+    c.sync(st);
     *nlaunch = 0; *algo_bytes = 0.0;
     const int nx = TD;
     int np = N;

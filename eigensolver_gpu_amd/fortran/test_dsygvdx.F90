@@ -3,8 +3,9 @@
 !     ./test_dsygvdx N            random symmetric positive-definite pair (seeded), eigenpairs 1..N/4
 !     ./test_dsygvdx fileA fileB  Fortran unformatted files: record 1 = n, m, lda; record 2 = A(1:n,1:n)
 !                                 (the format eigensolver_gpu_amd/io.py::write_matrix_file produces)
-! then one call of dsygvdx_gpu (:315-316) at the documented workspace minima, a residual check, and the public stage
-! modules dsygst_gpu / dsytrd_gpu / dsyevd_gpu called with the reference's argument lists.
+! then LAPACK dsygvd on the host (:186-210), one call of dsygvdx_gpu (:315-316) at the documented workspace minima, the
+! compare() report of the GPU result against the CPU one (:321-322) in the reference's format, a residual check, the batch
+! module, and the public stage modules dsygst_gpu / dsytrd_gpu / dsyevd_gpu called with the reference's argument lists.
 program test_dsygvdx
   use iso_c_binding
   use hip_min
@@ -14,6 +15,9 @@ program test_dsygvdx
   use dsyevd_gpu
   use dsygst_gpu
   use dsytrd_gpu
+  use dsygvdx_gpu_batch
+  use compare_utils
+  use lapack_host
   implicit none
   interface
     integer(c_int) function eigsolve_dpotrf(N, B, ldb, info) bind(C, name="eigsolve_dpotrf")
@@ -33,6 +37,10 @@ program test_dsygvdx
   integer(c_int) :: istat, pinfo
   real(8) :: res, t, tr
   integer(8) :: c0, c1, rate
+  real(8), allocatable, target :: A1(:,:), B1(:,:), w1(:), Zb(:,:,:), wb(:,:)
+  integer, parameter :: nbatch = 3
+  type(c_ptr), dimension(nbatch) :: Ab_d, Bb_d, Zb_d, wb_d, workb_d
+  integer :: binfo(nbatch), q
 
   nargs = command_argument_count()
   if (nargs == 1) then
@@ -69,6 +77,15 @@ program test_dsygvdx
   print*, "Running with N = ", N
   il = 1; iu = M
 
+  ! CASE 1: CPU (test_driver/test_dsygvdx.F90:186-210)
+  allocate(A1(lda,N), B1(lda,N), w1(N))
+  A1 = Aref; B1 = Bref
+  call system_clock(c0, rate)
+  call host_dsygvd(N, A1, lda, B1, lda, w1, info)
+  call system_clock(c1)
+  if (info /= 0) write(*,*) 'CPU dsygvd failed. istat = ', info
+  write(*,'(A,F12.3)') ' Time for CPU dsygvd = ', dble(c1 - c0) / dble(rate) * 1000.0d0
+
   call init_eigsolve_gpu()
   lwork = 1 + 6*N + 2*N*N; liwork = 3 + 5*N; lwork_d = 2*64*64 + 66*N
   allocate(work(lwork), iwork(liwork), Zh(lda,N), wh(N))
@@ -91,6 +108,9 @@ program test_dsygvdx
     write(*,*) 'dsygvdx_gpu failed'
     stop 1
   end if
+  print*, "evalues/evector accuracy: (compared to CPU results)"      ! test_dsygvdx.F90:321-322
+  call compare(w1, wh, iu)
+  call compare(A1, Zh, N, iu)
   res = resid(Aref, Bref, Zh, wh, M, .true.)
   write(*,'(A,I6,A,I6,A,F10.3,A,ES10.3,A,ES10.3)') ' N=', N, ' m=', M, '  Time for CUSTOM dsygvd/x = ', t, &
         ' ms   residual=', res, '  N*eps=', N * epsilon(1.0d0)
@@ -99,6 +119,33 @@ program test_dsygvdx
     write(*,*) 'RESIDUAL CHECK FAILED'
     stop 2
   end if
+
+  ! ---- a batch of problems in ONE call from this one thread (dsygvdx_gpu_batch) ---------------------------------------
+  allocate(Zb(lda,N,nbatch), wb(N,nbatch))
+  do q = 1, nbatch
+    istat = hipMalloc(Ab_d(q), int(8, c_size_t) * lda * N)
+    istat = hipMalloc(Bb_d(q), int(8, c_size_t) * lda * N)
+    istat = hipMalloc(Zb_d(q), int(8, c_size_t) * lda * N)
+    istat = hipMalloc(wb_d(q), int(8, c_size_t) * N)
+    istat = hipMalloc(workb_d(q), int(8, c_size_t) * lwork_d)
+    istat = hipMemcpy(Ab_d(q), c_loc(Aref), int(8, c_size_t) * lda * N, hipMemcpyHostToDevice)
+    istat = hipMemcpy(Bb_d(q), c_loc(Bref), int(8, c_size_t) * lda * N, hipMemcpyHostToDevice)
+  end do
+  call system_clock(c0, rate)
+  call dsygvdx_gpu_batch_solve(nbatch, N, Ab_d, lda, Bb_d, lda, Zb_d, lda, il, iu, wb_d, workb_d, lwork_d, Zb, lda, wb, binfo)
+  call system_clock(c1)
+  if (any(binfo /= 0)) then
+    write(*,*) 'dsygvdx_gpu_batch failed', binfo
+    stop 11
+  end if
+  do q = 1, nbatch
+    if (maxval(abs(wb(1:M,q) - wh(1:M))) > 0.0d0 .or. maxval(abs(Zb(1:N,1:M,q) - Zh(1:N,1:M))) > 0.0d0) then
+      write(*,*) 'dsygvdx_gpu_batch: problem', q, 'differs from the single call'
+      stop 12
+    end if
+  end do
+  write(*,'(A,I3,A,F10.3,A)') ' dsygvdx_gpu_batch: ', nbatch, ' problems in one call, ', dble(c1 - c0) / dble(rate) * 1000.0d0, &
+        ' ms, results identical to the single call'
 
   ! ---- public stage modules with the reference's argument lists -------------------------------------------
   ! unsupported combinations print and return, like dsygst_gpu.F90:43-46

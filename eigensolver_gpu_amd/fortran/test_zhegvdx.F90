@@ -1,7 +1,10 @@
 ! test_zhegvdx.F90 -- Fortran driver exercising the drop-in modules exactly like the reference's
 ! test program does (test_driver/test_zhegvdx.F90:266-303): random Hermitian-PD pair (recipe of
 ! :28-66, with this build's seeded generator), workspaces at the documented minima, one call of
-! zhegvdx_gpu, residual check.  Usage: ./test_zhegvdx [N] [m]
+! zhegvdx_gpu, residual check; like the reference's program the problem is first solved with LAPACK zhegvd on the host
+! (:160-184) and the GPU result is judged against it with compare() (:297-299), printed in the reference's report format;
+! then the batch module (three copies of the problem in one call) and the public stage modules.
+! Usage: ./test_zhegvdx [N] [m]
 program test_zhegvdx
   use iso_c_binding
   use hip_min
@@ -12,6 +15,9 @@ program test_zhegvdx
   use zhegst_gpu
   use zhetrd_gpu
   use eigsolve_laxlib_glue
+  use zhegvdx_gpu_batch
+  use compare_utils
+  use lapack_host
   implicit none
   interface
     integer(c_int) function eigsolve_zpotrf(N, B, ldb, info) bind(C, name="eigsolve_zpotrf")
@@ -36,6 +42,12 @@ program test_zhegvdx
   real(8) :: res, nrmA, t
   complex(8) :: s
   integer(8) :: c0, c1, rate
+  ! CPU LAPACK leg and batch call
+  complex(8), allocatable, target :: A1(:,:), B1(:,:), Zb(:,:,:)
+  real(8), allocatable, target :: w1(:), wb(:,:)
+  integer, parameter :: nbatch = 3
+  type(c_ptr), dimension(nbatch) :: Ab_d, Bb_d, Zb_d, wb_d, workb_d, rworkb_d
+  integer :: binfo(nbatch), q
 
   N = 512; m = 128
   nargs = command_argument_count()
@@ -50,6 +62,15 @@ program test_zhegvdx
   allocate(A(N,N), B(N,N), T1(N,N), Zh(N,N), wh(N))
   call make_pd(A, 1000 + N, 0.0d0)
   call make_pd(B, 2000 + N, dble(N))
+
+  ! CASE 1: CPU (test_driver/test_zhegvdx.F90:160-184; one call, the reference times a second one) -------------------
+  allocate(A1(N,N), B1(N,N), w1(N))
+  A1 = A; B1 = B
+  call system_clock(c0, rate)
+  call host_zhegvd(N, A1, lda, B1, lda, w1, info)
+  call system_clock(c1)
+  if (info /= 0) write(*,*) 'CPU zhegvd failed. istat = ', info
+  write(*,'(A,F12.3)') ' Time for CPU zhegvd = ', dble(c1 - c0) / dble(rate) * 1000.0d0
 
   call init_eigsolve_gpu()
   lwork = N; lrwork = 1 + 5*N + 2*N*N; liwork = 3 + 5*N
@@ -75,6 +96,9 @@ program test_zhegvdx
     write(*,*) 'zhegvdx_gpu failed'
     stop 1
   end if
+  print*, "evalues/evector accuracy: (compared to CPU results)"      ! test_zhegvdx.F90:297-299
+  call compare(w1, wh, iu)
+  call compare(A1, Zh, N, iu)
 
   ! residual || A Z - B Z diag(w) ||_F / ||A||_F   (A, B regenerated: the call destroys them)
   res = 0; nrmA = 0
@@ -100,6 +124,35 @@ program test_zhegvdx
     write(*,*) 'RESIDUAL CHECK FAILED'
     stop 2
   end if
+
+  ! ---- a batch of problems in ONE call from this one thread (zhegvdx_gpu_batch: the library keeps them in flight) ----------
+  allocate(Zb(N,N,nbatch), wb(N,nbatch))
+  do q = 1, nbatch
+    istat = hipMalloc(Ab_d(q), int(16, c_size_t) * N * N)
+    istat = hipMalloc(Bb_d(q), int(16, c_size_t) * N * N)
+    istat = hipMalloc(Zb_d(q), int(16, c_size_t) * N * N)
+    istat = hipMalloc(wb_d(q), int(8, c_size_t) * N)
+    istat = hipMalloc(workb_d(q), int(16, c_size_t) * lwork_d)
+    istat = hipMalloc(rworkb_d(q), int(8, c_size_t) * lrwork_d)
+    istat = hipMemcpy(Ab_d(q), c_loc(A), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+    istat = hipMemcpy(Bb_d(q), c_loc(B), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)
+  end do
+  call system_clock(c0, rate)
+  call zhegvdx_gpu_batch_solve(nbatch, N, Ab_d, lda, Bb_d, lda, Zb_d, lda, il, iu, wb_d, workb_d, lwork_d, rworkb_d, lrwork_d, &
+                               Zb, lda, wb, binfo)
+  call system_clock(c1)
+  if (any(binfo /= 0)) then
+    write(*,*) 'zhegvdx_gpu_batch failed', binfo
+    stop 9
+  end if
+  do q = 1, nbatch
+    if (maxval(abs(wb(1:m,q) - wh(1:m))) > 0.0d0 .or. maxval(abs(Zb(:,1:m,q) - Zh(:,1:m))) > 0.0d0) then
+      write(*,*) 'zhegvdx_gpu_batch: problem', q, 'differs from the single call'
+      stop 10
+    end if
+  end do
+  write(*,'(A,I3,A,F10.3,A)') ' zhegvdx_gpu_batch: ', nbatch, ' problems in one call, ', dble(c1 - c0) / dble(rate) * 1000.0d0, &
+        ' ms, results identical to the single call'
 
   ! the LAXlib call pattern (cdiaghg_gpu): H, S stay intact on the device, results stay on the device
   istat = hipMemcpy(A_d, c_loc(A), int(16, c_size_t) * N * N, hipMemcpyHostToDevice)

@@ -482,6 +482,16 @@ def test_full_size_properties(env, cfg):
     assert oracle.compare_1d(wl, w[:m])[0] <= 1e-12
 
 
+def _check_compare_lines(stdout, tol_w, tol_z):
+    """The two report lines of compare() after 'evalues/evector accuracy' (eigenvalues, |eigenvectors| vs CPU LAPACK ?hegvd)."""
+    lines = stdout.splitlines()
+    k = [i for i, l in enumerate(lines) if "evalues/evector accuracy" in l][0]
+    rep = [l for l in lines[k + 1:k + 3]]
+    assert len(rep) == 2
+    for l, tol in zip(rep, (tol_w, tol_z)):
+        assert "EXACT MATCH" in l or (l.split()[0] == "l2norm" and float(l.split()[2]) <= tol), l
+
+
 def test_fortran_dropin_driver(env):
     """The Fortran modules zhegvdx_gpu / eigsolve_vars / nvtx_inters (same names and argument order as
     the reference) called from a Fortran program built with amdflang, like test_driver/test_zhegvdx.F90."""
@@ -496,6 +506,10 @@ def test_fortran_dropin_driver(env):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASSED" in out.stdout
     assert "cdiaghg_gpu_glue: eigenvalues identical" in out.stdout     # LAXlib-style glue module (8(f) row 4)
+    # the reference driver's CPU leg + compare() report (test_zhegvdx.F90:160-184, 297-299) and the batch module
+    assert "Time for CPU zhegvd" in out.stdout
+    _check_compare_lines(out.stdout, 1e-12, 1e-8)
+    assert "zhegvdx_gpu_batch:   3 problems in one call" in out.stdout and "identical to the single call" in out.stdout
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1176,6 +1190,9 @@ def test_fortran_real_driver_random_and_file_input(env, tmp_path):
     out = subprocess.run([exe, "256"], capture_output=True, text=True, env=envv, timeout=300)
     assert out.returncode == 0 and "PASSED" in out.stdout, out.stdout + out.stderr
     assert "Provided itype/uplo not supported!" in out.stdout      # dsygst_gpu(2, ...) prints and returns
+    assert "Time for CPU dsygvd" in out.stdout                     # test_dsygvdx.F90:186-210
+    _check_compare_lines(out.stdout, 1e-12, 1e-8)                  # :321-322
+    assert "dsygvdx_gpu_batch:   3 problems in one call" in out.stdout and "identical to the single call" in out.stdout
     n, m = 200, 37
     A = oracle.gen_spd(n, 5200, False)
     B = oracle.gen_spd(n, 5300, False, shift=float(n))
@@ -1246,12 +1263,16 @@ def test_real_path_il_quirk_option(env):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("workers", [3, 0])
 @pytest.mark.parametrize("n,m,nprob", [(130, 40, 2), (300, 75, 3), (97, 97, 5), (1100, 200, 2)])
-def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob):
-    """eigsolve_?hegvdx_batch / ?sygvdx_batch: nprob problems of one order, tridiagonalizations in lockstep (every per-column
-    launch carries all problems).  Eigenvalues, eigenvectors, the factor left in B and the preserved strict lower triangle
-    of A must be bit-identical to nprob calls of the single-problem driver (5 problems: more than one lockstep group)."""
+def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, workers):
+    """eigsolve_?hegvdx_batch / ?sygvdx_batch: nprob problems of one order in one call from one thread -- on the library's
+    worker threads (default, `batch_workers` problems in flight, each an ordinary single solve on its own context) or,
+    batch_workers = 0, on the caller's context with the tridiagonalizations in lockstep (every per-column launch carries
+    all problems; 5 problems: more than one lockstep group).  Eigenvalues, eigenvectors, the factor left in B and the
+    preserved strict lower triangle of A must be bit-identical to nprob calls of the single-problem driver."""
     torch, oracle, api = env
+    assert api.set_option("batch_workers", workers) == 0
     probs = [(oracle.gen_spd_fast(n, 8800 + 31 * q + n, cplx), oracle.gen_spd_fast(n, 9900 + 37 * q + n, cplx, shift=float(n)))
              for q in range(nprob)]
 
@@ -1268,7 +1289,10 @@ def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob):
         single.append((ws.w_h.clone(), ws.Z_h.clone(), Ad.clone(), Bd.clone()))
     pairs = [(dev(A), dev(B)) for A, B in probs]
     wss = [api.Workspace(n, cplx) for _ in range(nprob)]
-    infos = api.hegvdx_batch(pairs, 1, m, wss)
+    try:
+        infos = api.hegvdx_batch(pairs, 1, m, wss)
+    finally:
+        api.set_option("batch_workers", 3)
     assert infos == [0] * nprob
     for q in range(nprob):
         w1, Z1, A1, B1 = single[q]
@@ -1281,17 +1305,27 @@ def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob):
         assert oracle.residual(*probs[q], w, Z) <= n * EPS
 
 
-def test_batch_driver_error_reporting(env):
-    """One problem of the batch has a B that is not positive definite: info = -1 for that problem only, the others are solved."""
+@pytest.mark.parametrize("workers", [3, 0])
+def test_batch_driver_error_reporting(env, workers):
+    """One problem of the batch has a B that is not positive definite: info = -1 for that problem only, the others are
+    solved; a null entry in the pointer arrays is rejected with info = -1 for every problem (no dereference)."""
     torch, oracle, api = env
     n, m = 150, 30
+    api.set_option("batch_workers", workers)
     A = [oracle.gen_spd_fast(n, 500 + q, True) for q in range(3)]
     B = [oracle.gen_spd_fast(n, 600 + q, True, shift=float(n)) for q in range(3)]
     B[1][70, 70] = -3.0
     pairs = [(api.to_device(np.triu(a)), api.to_device(np.triu(b))) for a, b in zip(A, B)]
     wss = [api.Workspace(n, True) for _ in range(3)]
-    infos = api.hegvdx_batch(pairs, 1, m, wss)
-    assert infos == [0, -1, 0]
-    for q in (0, 2):
-        Z = np.asfortranarray(api.to_host(wss[q].Z_h, n, m))
-        assert oracle.residual(A[q], B[q], wss[q].w_h.numpy()[:n], Z) <= n * EPS
+    try:
+        infos = api.hegvdx_batch(pairs, 1, m, wss)
+        assert infos == [0, -1, 0]
+        for q in (0, 2):
+            Z = np.asfortranarray(api.to_host(wss[q].Z_h, n, m))
+            assert oracle.residual(A[q], B[q], wss[q].w_h.numpy()[:n], Z) <= n * EPS
+        pairs = [(api.to_device(np.triu(a)), api.to_device(np.triu(b))) for a, b in zip(A, B)]
+        assert api.hegvdx_batch(pairs, 1, m, wss, null_entry="Z_h") == [-1, -1, -1]
+        assert api.hegvdx_batch(pairs, 1, m, wss, null_entry="w_h") == [-1, -1, -1]
+        assert torch.equal(pairs[0][0], api.to_device(np.triu(A[0])))        # nothing was touched
+    finally:
+        api.set_option("batch_workers", 3)
