@@ -6,9 +6,10 @@ embarrassingly: one process per GPU (torch.distributed, backend "nccl" = RCCL ov
 block-cyclic assignment, NO collective on the data path.  RCCL is used only for the optional
 gather of results and for the benchmark's timing reduction.
 
-Inside one process several problems are kept in flight on the GPU by a small pool of PERSISTENT host
-threads: the library keeps one context (streams, events, cached scratch) per (host thread, device), so the
-threads must live as long as the batch does -- a context dies with its thread."""
+Inside one process several problems are kept in flight on the GPU either by the library itself (eigsolve_?hegvdx_batch:
+one call from one host thread, the library's worker threads keep `batch_workers` problems in flight -- the default of
+bench.py) or by a small pool of PERSISTENT host threads issuing one-problem calls (InflightPool): the library keeps one
+context (events, cached scratch) per (host thread, device), so such threads should live as long as the batch does."""
 import queue
 import threading
 
@@ -16,6 +17,12 @@ import threading
 def shard_problems(n_problems, rank, world):
     """Static block-cyclic partition p -> rank (p mod world)."""
     return [p for p in range(n_problems) if p % world == rank]
+
+
+def host_threads_per_rank(cores, world):
+    """Host LAPACK / BLAS threads one rank may use when `world` ranks share a node's cores (the host-side
+    tridiagonal step of 8 ranks must not oversubscribe the CPU).  Capped at 64: OpenBLAS stops scaling long before."""
+    return max(1, min(64, int(cores) // max(int(world), 1)))
 
 
 class InflightPool:
@@ -28,11 +35,9 @@ class InflightPool:
         self._in = [queue.Queue() for _ in range(self.nthr)]
         self._out = queue.Queue()
         self._threads = []
-        # Workers are started ONE AT A TIME, each finishing its init (where the library context -- two HIP streams -- is
-        # created) before the next starts: HIP deals streams round-robin onto the process' hardware queues, so the order of
-        # creation decides which solves share a queue.  With the ROCm default of 4 queues, sequential creation puts two of
-        # three workers on one queue and the third on another (15.7 problems/s at C3); a racy creation order can spread them
-        # over three queues (11.7, measured: three dependent-launch chains on three hardware queues slow each other down).
+        # Workers are started one at a time, each finishing its init before the next starts (deterministic context order).
+        # (Round 2 needed this to steer which hardware queue a worker's streams landed on; since round 3 the library leases
+        #  one stream per call from a process-wide pool and the order no longer matters.)
         for t in range(self.nthr):
             ready = threading.Event()
             th = threading.Thread(target=self._run, args=(t, init, ready), daemon=True)

@@ -39,8 +39,9 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance"};
- * value<=0 restores the default ("tridiag": value<0).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance","batch_workers"};
+ * value<=0 restores the default, except where 0 is itself a setting: "tridiag", "gst", "overlap" (value<0 restores the
+ * default), "potrf" (0 = recursive form, anything else = block rows), "batch_workers" (0 = lockstep form, value<0 or >16 = default 3).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
  * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
@@ -48,7 +49,9 @@ int eigsolve_set_host_threads(int nthreads);
  * potrf with the first half of gst, bit 1 = larft T factors with the tridiagonal eigensolver (zheevd_gpu.F90:125
  * overlaps the same work).  Measured on MI355X: once a context drives two hardware queues every dependent launch
  * gets slower (bit 1 alone: back-transform -1.1 ms, whole solve +13 ms), so 0 (default) = single stream.
- * "bt_nb": 64 (the reference's larfb width) or 128 (default: two 64-blocks with a merged T factor).
+ * "bt_nb": reflectors per block of the back-transformation: 64 (the reference's larfb width), 128, 256 (default) or 512 --
+ * 64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
+ * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default 3; 0 = lockstep form).
  * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
  * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
  * larger than "gst_thr" (default 1024), two solves below.
@@ -98,13 +101,19 @@ int eigsolve_dsygvdx(int N, double *A_d, int lda, double *B_d, int ldb, double *
                      double *w_d, double *work_d, int lwork, double *work_h, int lwork_h, int *iwork_h,
                      int liwork_h, double *Z_h, int ldz_h, double *w_h, int *info, int skip_host_copy);
 
-/* Batch of nprob problems of ONE order (QE k-point style, BASELINE.json configs[4]) solved by one call on the calling thread's
- * context: the tridiagonalizations run in LOCKSTEP (every per-column launch carries all problems), the other phases problem after
- * problem.  Arguments as eigsolve_zhegvdx / eigsolve_dsygvdx with one pointer per problem (host arrays of nprob device / host
- * pointers); the same workspace minima per problem (lwork, lrwork); no host workspaces: the batch driver uses the device
- * tridiagonal solver ("tridiag" = 1, the default).  info[q] = 0 / -1 per problem; return value -1 if any problem failed.
- * Per-problem results are bit-identical to the single-problem driver's.  The reference has no counterpart (one problem per
- * call, zhegvdx_gpu.F90:75); this is the batch extension announced in SURVEY.md 8(b) "Threading". */
+/* Batch of nprob problems of ONE order (QE k-point style, BASELINE.json configs[4]) solved by one call from one host thread.
+ * The library keeps "batch_workers" (default 3) of the problems in flight on its own worker threads -- the caller's thread
+ * is one of them --, each problem an ordinary single-problem solve on a context and stream of its own, so that the
+ * latency-bound phases of one solve fill under the kernels of the others (C3: 16.0 problems/s against 10.3 for one call
+ * per problem).  "batch_workers" = 0: everything on the caller's context, the tridiagonalizations in LOCKSTEP (every
+ * per-column launch carries all problems), the other phases problem after problem.  Arguments as eigsolve_zhegvdx /
+ * eigsolve_dsygvdx with one pointer per problem (host arrays of nprob device / host pointers, no null entries; Z_h may be
+ * NULL only with skip_host_copy); the same workspace minima per problem (lwork, lrwork); no host workspaces: the batch
+ * driver uses the device tridiagonal solver ("tridiag" = 1, the default).  info[q] = 0 / -1 per problem; return value -1 if
+ * any problem failed or the arguments were rejected (then every info[q] = -1).  Per-problem results are bit-identical to
+ * the single-problem driver's in both forms, all options included.  The reference has no counterpart (one problem per
+ * call, zhegvdx_gpu.F90:75); this is the batch extension announced in SURVEY.md 8(b) "Threading".  Fortran:
+ * modules zhegvdx_gpu_batch / dsygvdx_gpu_batch. */
 int eigsolve_zhegvdx_batch(int nprob, int N, void *const *A_d, int lda, void *const *B_d, int ldb, void *const *Z_d, int ldz,
                            int il, int iu, double *const *w_d, void *const *work_d, int lwork, double *const *rwork_d,
                            int lrwork, void *const *Z_h, int ldz_h, double *const *w_h, int *info, int skip_host_copy);

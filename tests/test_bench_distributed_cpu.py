@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the batch path bench.py uses for the multi-GPU legs (no GPU here): the SAME functions --
+"""world_size-2 and world_size-8 gloo tests of the batch path bench.py uses for the multi-GPU legs (no GPU here): the SAME functions --
 batch.shard_problems / InflightPool / run_sharded_batch / gather_eigenvalues -- driven with a CPU stub solver.
 Problems are partitioned p -> rank (p mod G) with no data-path collective; the only collectives are the timing
 all_gather and the result gather."""
@@ -16,8 +16,12 @@ SCRIPT = textwrap.dedent("""
     from eigensolver_gpu_amd.batch import InflightPool, shard_problems, run_sharded_batch, gather_eigenvalues
     dist.init_process_group(backend="gloo")
     r, w = dist.get_rank(), dist.get_world_size()
-    NP, M = 13, 4
+    NP, M = (64, 4) if w == 8 else (13, 4)          # world 8: BASELINE configs[4], 64 problems -> 8 per rank
     mine = shard_problems(NP, r, w)
+    if w == 8:
+        assert len(mine) == 8 and mine == list(range(r, 64, 8))
+        from eigensolver_gpu_amd.batch import host_threads_per_rank
+        assert host_threads_per_rank(256, 8) == 32 and host_threads_per_rank(8, 8) == 1 and host_threads_per_rank(4, 8) == 1
     allp = [None] * w
     dist.all_gather_object(allp, mine)
     assert sorted(sum(allp, [])) == list(range(NP))
@@ -74,8 +78,21 @@ def test_two_rank_gloo(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+def test_eight_rank_gloo(tmp_path):
+    """The 8-way split a driver with an 8-GPU node will run (no such node here): 64 problems -> 8 per rank, p -> rank p mod 8,
+    gathered [64, m] on rank 0, max-over-ranks timing reduction -- the same batch.py functions, 8 gloo ranks on the CPU."""
+    f = tmp_path / "w8.py"
+    f.write_text(SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", str(f)],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 8
+
+
 def test_bench_uses_the_batch_module():
     """bench.py's multi-GPU legs go through eigensolver_gpu_amd/batch.py (the functions the gloo test drives)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems"):
+    for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems", "host_threads_per_rank"):
         assert name in src

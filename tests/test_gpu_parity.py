@@ -1221,7 +1221,7 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--order", "512",
            "--share-gpu", "--backend", "gloo", "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag", "--inflight", "2",
-           "--batch", "2"]
+           "--batch", "2", "--fuse", "1"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -1234,13 +1234,43 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     # the C5 workload as the timed region (strong scaling: 64 problems over the ranks), at a small order
     cmd2 = cmd[:cmd.index(os.path.join(root, "bench.py")) + 1] + [
         "--gpus", "2", "--workload", "c5", "--steps", "1", "--warmup", "1", "--order", "256", "--share-gpu", "--backend", "gloo",
-        "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag", "--inflight", "2"]
+        "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag"]        # default mode: one host thread, in-library batch
     cmd2[cmd2.index("29531")] = "29532"
     out = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["config"]["problems_per_step_total"] == 64 and d["config"]["problems_per_gpu_per_step"] == 32
     assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
+
+
+def test_bench_eight_ranks_on_one_gpu(env):
+    """world = 8 without 8 GPUs: bench.py under torchrun with 8 ranks sharing GPU 0 (gloo), C5's 64 problems -> 8 per rank at
+    order 256, gather shape [64, m], max-over-ranks timing; and the default line with its c5 object at a small order."""
+    import json
+    import subprocess
+    import sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "8", "--share-gpu", "--backend", "gloo",
+            "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag", "--isolated-reps", "1"]
+    envv = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    out = subprocess.run(base + ["--workload", "c5", "--steps", "1", "--warmup", "1", "--order", "256"], capture_output=True, text=True,
+                         timeout=1200, env=envv)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong"
+    assert d["config"]["problems_per_step_total"] == 64 and d["config"]["problems_per_gpu_per_step"] == 8
+    assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
+    assert len(d["rank_elapsed_ms_min_max"]) == 2 and d["rank_elapsed_ms_min_max"][1] * 1e-3 * d["value"] <= 64.0 * 1.0001
+    base[base.index("29541")] = "29542"
+    out = subprocess.run(base + ["--steps", "1", "--warmup", "1", "--order", "256", "--c5-order", "256"], capture_output=True, text=True,
+                         timeout=1200, env=envv)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["config"]["problems_per_step_total"] == 24 and d["eigenvalues_gathered"] == [24, 64]
+    assert d["c5"]["gathered_eigenvalues_shape"] == [64, 64] and d["c5"]["problems_per_gpu"] == 8
+    assert d["c5"]["rerun_bit_identical"] is True and len(d["c5"]["pass_ms_min_median_max"]) == 3
 
 
 def test_real_path_il_quirk_option(env):
