@@ -543,6 +543,324 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     TSTAMP(0, 5, T0);
 }
 
+// ------------------------------------------------------------------------------------------
+// panel_col_kernel : ONE launch per column for the tail of the reduction (order <= "trd_fuse_n").
+//
+// Up to n ~ 1300 (complex) a column's two kernels cost 4.3-5 us each whatever the work: launch ramp, one dependent memory
+// round trip, a kernel boundary.  Here the row work of panel_row_kernel is folded into the mat-vec launch: a workgroup owns
+// one 64x64 tile (I, J) of the upper triangle and FIRST derives, redundantly, the 2 x 64 entries x_I, x_J of the updated
+// column it is about to multiply with (finishing W(:, c) for those rows on the way) from data of the previous launch --
+// O((2 npo + nt) x 128) values from L2 -- while its tile is already in flight from HBM.  Diagonal tiles are the OWNERS of
+// their 64 rows: only they store W(:, c), the finished reflector v_c, the raw new column and the per-block partial sums.
+//
+// What makes one launch per column possible is linearity: v = scale * xh + e_(n-1) (xh = raw column, last entry zeroed).
+// scale needs ||xh|| -- a reduction over ALL rows, i.e. over all workgroups of the launch that produces xh -- so a launch
+// never applies its own column's scalars: it multiplies the tile with the RAW xh and publishes raw partials
+//     P^  = A xh (per tile stripe),  S^ = xh^H A xh,  D^ = xh^H A(:, n-1),  Z^ = [V W]^H xh (per owner block),  ||xh||^2,
+// and the NEXT launch, which can sum the norm partials, reconstructs
+//     y = scale P^ + A(:, n-1),   z = scale Z^ + [V W](n-1, :)^H,   v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
+// before it finishes W(:, c) = tau (y - V z2' - W z1') + alpha v_c exactly as panel_row_kernel does (zhetrd_gpu.F90:335-511,
+// :750-879).  Partial-sum buffers are double (a launch reads the previous column's set and writes its own).
+//   FIRST   : first column of a panel -- nothing to finish, x = A(:, i) as the trailing update left it;
+//   FINONLY : after the last column of a panel -- only the owners run: W(:, c), v_c, e, tau; no new column, no mat-vec.
+// ------------------------------------------------------------------------------------------
+template <class T> struct ColArgs {
+    T* A; int lda;
+    T* W; int ldw;
+    int np, nb, i;           // i = column generated by this launch (c = i + 1 is finished by it); FINONLY: i = c - 1
+    double* e; T* tau;
+    // set of the previous launch (describes column c) / set written by this launch (describes column i)
+    const T* xprev; T* xnew;
+    const T* Pp; T* Pn; int ldp;
+    const T* Sp; T* Sn;
+    const T* Dp; T* Dn;
+    const double* NPp; double* NPn;
+    const T* Zpp; T* Zpn;
+    const T* alphap; T* alphan;
+};
+template <class T, int NB> struct ColBatch {
+    ColArgs<T> p[NB];
+};
+
+template <class T, int NB, bool FIRST, bool FINONLY>
+__global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
+    const ColArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
+    const int i = a.i, c = i + 1;
+    const int n = i;                                   // order of the mat-vec: v_i has rows 0 .. i-1
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T zero = Tr<T>::zero();
+    int I, J;
+    if (FINONLY) { I = J = (int)blockIdx.x; }
+    else tile_decode((int)blockIdx.x, I, J);
+    const bool owner = (I == J);
+    const int r0 = I * HT, c0 = J * HT;
+    const int wbase = a.np - a.nb;
+    const int npo = FIRST ? 0 : a.np - 1 - c;          // panel columns older than c
+    const int ntc = (c + HT - 1) / HT;                 // 64-row blocks of the previous launch (order c)
+
+    __shared__ T zs[2][2][NBMAX];                      // [which][half][kk] gathered partial sums of Z^
+    __shared__ T z1f[NBMAX + 1], z2f[NBMAX + 1];       // final z1, z2 (wave 0 writes, all read after the barrier)
+    __shared__ T rowW[NBMAX + 1], rowV[NBMAX + 1];
+    __shared__ T s4[4], d4s[4];
+    __shared__ T part[2][4][3][HT];                    // [block sel][sub][psum / acc2 / acc3][row]
+    __shared__ T xs[2][HT];                            // raw new column: rows of block I / block J
+    __shared__ T scal[4];                              // scale, tau, alpha (wave 0 -> everybody)
+    __shared__ T redy[4][HT], redt[HT];
+    __shared__ T vcs[HT], wcs[HT];                     // v_c, w_c of the owner's rows (for the Z^ partials)
+
+    // ---------------- tile loads first: they fly during everything below ----------------
+    T av[16];
+    if constexpr (!FINONLY) {
+        const size_t roff = (size_t)min(r0 + lane, max(n - 1, 0));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, max(n - 1, 0)) * a.lda];
+    }
+
+    // ---------------- scalars of column c (every workgroup, from the previous launch's partial sums) ----------------
+    T scale = Tr<T>::one(), tau = zero, alpha = zero;
+    if constexpr (!FIRST) {
+        const int ntl = ntc * (ntc + 1) / 2;           // tiles (= S^ partials) of the previous launch
+        // gather: S^ over all threads, D^ / norm partials by every wave (<= 32 + values), Z^ split over the 4 waves
+        T Ssum = zero;
+        for (int q = tid; q < ntl; q += 256) Ssum = Ssum + a.Sp[q];
+        Ssum = wave_sum(Ssum);
+        const int which = wave & 1, half = wave >> 1;
+        T zsum = zero;
+        if (lane < npo)
+            for (int q = half; q < ntc; q += 2) zsum = zsum + a.Zpp[(size_t)(q * 2 + which) * NBMAX + lane];
+        if (lane < npo) zs[which][half][lane] = zsum;
+        if (lane == 0) s4[wave] = Ssum;
+        // row i = c - 1 of the panel (the e_(n-1) part of z, and the row needed for w_i), loaded by wave 0
+        T l_ww = zero, l_wv = zero, l_p = zero;
+        double npv = 0.0;
+        T dv = zero;
+        if (wave == 0) {
+            if (lane < npo) {
+                const int k = c + 1 + lane;
+                l_ww = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
+                l_wv = a.A[(size_t)i + (size_t)k * a.lda];
+            }
+            for (int q = lane; q < ntc; q += 64) {
+                l_p = l_p + a.Pp[(size_t)q * a.ldp + i];
+                npv += a.NPp[q];
+                dv = dv + a.Dp[q];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const double ss = wave_sum(npv);
+            const T alpha_e = *a.alphap;
+            double beta;
+            larfg_scalars<T>(ss, alpha_e, beta, tau, scale);
+            if (blockIdx.x == 0 && lane == 0) { a.e[c - 1] = beta; a.tau[c - 1] = tau; }
+            const T Dsum = wave_sum(dv);
+            const T Sraw = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            const double aLL = real_(a.A[(size_t)i + (size_t)i * a.lda]);
+            // v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
+            T cs = zero;
+            fmac_(cs, scale, Dsum);
+            const double S = abs2_(scale) * real_(Sraw) + 2.0 * real_(cs) + aLL;
+            T z1l = zero, z2l = zero;
+            if (lane < npo) {
+                z1l = scale * (zs[0][0][lane] + zs[0][1][lane]) + conj_(l_wv);
+                z2l = scale * (zs[1][0][lane] + zs[1][1][lane]) + conj_(l_ww);
+            }
+            T t = zero;
+            fmac_(t, z1l, z2l);
+            const double zz = wave_sum(real_(t));
+            alpha = Tr<T>::make((-0.5 * abs2_(tau)) * (S - 2.0 * zz), 0.0);
+            if constexpr (Tr<T>::cx) {
+                // (v^H A v is real for Hermitian A; the reference form alpha = -1/2 tau (w^H v) reduces to this)
+            }
+            // w_i = W(i, c): row i of the column being finished;  y_i = scale P^(i) + A(i, i)
+            const T yi = scale * wave_sum(l_p) + Tr<T>::make(aLL, 0.0);
+            const T u = wave_sum(sel(lane == 0, yi, zero) - (l_ww * z1l + l_wv * z2l));
+            const T wi = tau * u + alpha;              // v_c(i) = 1
+            if (lane < npo) { z1f[lane] = z1l; z2f[lane] = z2l; rowW[lane] = conj_(l_ww); rowV[lane] = conj_(l_wv); }
+            if (lane == 0) { rowW[npo] = conj_(wi); rowV[npo] = Tr<T>::one(); scal[0] = scale; scal[1] = tau; scal[2] = alpha; }
+        }
+        __syncthreads();
+        scale = scal[0]; tau = scal[1]; alpha = scal[2];
+    }
+
+    // ---------------- row work: x_I (and x_J), finishing W(:, c) for those rows ----------------
+    // off-diagonal tile: waves 0,1 -> rows of block I, waves 2,3 -> rows of block J, the two waves of a block split the
+    // panel columns / stripes by parity; diagonal tile (and FINONLY): all four waves on block I, split four ways.
+    const int bsel = owner ? 0 : (wave >> 1);
+    const int nsub = owner ? 4 : 2;
+    const int sub = owner ? wave : (wave & 1);
+    const int rb0 = (bsel == 0) ? r0 : c0;
+    const int r = rb0 + lane;
+    const int rows = i + 1;                            // rows 0 .. i of the panel are live
+    const bool active = r < rows;
+    const size_t rc = (size_t)min(r, rows - 1);
+    T xr_new = zero, wr = zero, vr = zero;
+    if constexpr (FIRST) {
+        T acur = a.A[rc + (size_t)i * a.lda];
+        if (r == i) acur = Tr<T>::realpart(acur);
+        xr_new = sel(active, acur, zero);
+    } else {
+        T psum = zero, acc2 = zero, acc3 = zero;
+        for (int q = sub; q < ntc; q += nsub) psum = psum + a.Pp[(size_t)q * a.ldp + rc];
+#pragma unroll 4
+        for (int kk = sub; kk < npo; kk += nsub) {
+            const int k = c + 1 + kk;
+            const T vv = a.A[rc + (size_t)k * a.lda];
+            const T wv = a.W[rc + (size_t)(k - wbase) * a.ldw];
+            acc2 = acc2 - (wv * z1f[kk] + vv * z2f[kk]);
+            if constexpr (!FINONLY) acc3 = acc3 + (vv * rowW[kk] + wv * rowV[kk]);
+        }
+        part[bsel][sub][0][lane] = psum;
+        part[bsel][sub][1][lane] = acc2;
+        part[bsel][sub][2][lane] = acc3;
+        const T xc_raw = a.xprev[rc];
+        T acur = a.A[rc + (size_t)i * a.lda];          // column i: A(r, n_c - 1) for y AND the column to update
+        if (r == i) acur = Tr<T>::realpart(acur);
+        __syncthreads();
+        T ps = part[bsel][0][0][lane] + part[bsel][1][0][lane];
+        T a2 = part[bsel][0][1][lane] + part[bsel][1][1][lane];
+        T a3 = part[bsel][0][2][lane] + part[bsel][1][2][lane];
+        if (owner) {
+            ps = ps + (part[0][2][0][lane] + part[0][3][0][lane]);
+            a2 = a2 + (part[0][2][1][lane] + part[0][3][1][lane]);
+            a3 = a3 + (part[0][2][2][lane] + part[0][3][2][lane]);
+        }
+        vr = (r < c - 1) ? scale * xc_raw : ((r == c - 1) ? Tr<T>::one() : zero);
+        const T y = scale * ps + acur;
+        wr = tau * (y + a2) + alpha * vr;
+        if constexpr (!FINONLY) {
+            const T upd = a3 + (vr * rowW[npo] + wr * rowV[npo]);
+            T anew = acur - upd;
+            if (r == i) anew = Tr<T>::realpart(anew);
+            xr_new = sel(active, anew, zero);
+        }
+        if (owner && wave == 0 && active) {            // owners publish the finished column c
+            a.W[(size_t)r + (size_t)(c - wbase) * a.ldw] = wr;
+            a.A[(size_t)r + (size_t)c * a.lda] = vr;
+        }
+    }
+    if constexpr (FINONLY) return;
+
+    // ---------------- publish the raw new column (LDS for this tile, global by the owners) ----------------
+    const int nz = n - 1;                              // xh: rows >= nz are zero
+    if (owner) {
+        if (wave == 0) { xs[0][lane] = xr_new; xs[1][lane] = xr_new; vcs[lane] = vr; wcs[lane] = wr; }
+    } else if ((wave & 1) == 0) {
+        xs[bsel][lane] = xr_new;
+    }
+    if (owner && wave == 0) {
+        if (active) {
+            a.xnew[r] = xr_new;
+            if (r == i - 1) *a.alphan = xr_new;
+        }
+        const T alast = a.A[(size_t)min(r, max(n - 1, 0)) + (size_t)max(n - 1, 0) * a.lda];   // A(r, n-1), used for r < nz
+        double nrm = (active && r <= i - 2) ? abs2_(xr_new) : 0.0;
+        T dd = zero;
+        if (active && r < nz) fmac_(dd, xr_new, alast);
+        nrm = wave_sum(nrm);
+        dd = wave_sum(dd);
+        if (lane == 0) { a.NPn[I] = nrm; a.Dn[I] = dd; }
+    }
+    __syncthreads();
+
+    // ---------------- the tile: y_I += A_IJ xh_J,  y_J += A_IJ^H xh_I  (as panel_mv_kernel, raw xh) ----------------
+    {
+        const bool diag = owner;
+        const int rr = r0 + lane;
+        const T xr = sel(rr < nz, xs[0][lane], zero);
+        const bool interior = !diag && r0 + HT <= n && c0 + HT <= n && c0 + HT <= nz;
+        T yI = zero;
+        auto half = [&](int jb, T& w0, T& w1) {
+            T tj[8];
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    fma_(yI, av[jb + j], xs[1][wave * 16 + jb + j]);
+                    T p = zero;
+                    fmac_(p, av[jb + j], xr);
+                    tj[j] = p;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int cc = c0 + wave * 16 + jb + j;
+                    const bool ok = (rr < n) && (cc < n) && (!diag || rr <= cc);
+                    const bool dg = diag && rr == cc;
+                    T v = sel(ok, av[jb + j], zero);
+                    v = sel(dg, Tr<T>::realpart(v), v);
+                    fma_(yI, v, sel(cc < nz, xs[1][wave * 16 + jb + j], zero));
+                    T p = zero;
+                    fmac_(p, sel(dg, zero, v), xr);
+                    tj[j] = p;
+                }
+            }
+            transpose_reduce8_phase1<T>(tj, w0, w1);
+        };
+        T wa0, wa1, wb0, wb1;
+        half(0, wa0, wa1);
+        half(8, wb0, wb1);
+        const T tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
+        redy[wave][lane] = yI;
+        if ((lane & 3) == 0) redt[wave * 16 + transpose_col_of_lane(lane)] = tval;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const T yv = (redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane]);
+        const T tv = redt[lane];
+        const T xI = sel(r0 + lane < nz, xs[0][lane], zero);
+        const T xJ = sel(c0 + lane < nz, xs[1][lane], zero);
+        T Sacc = zero;
+        if (owner) {
+            const T sm = yv + tv;
+            a.Pn[(size_t)J * a.ldp + r0 + lane] = sm;
+            fmac_(Sacc, xI, sm);
+        } else {
+            a.Pn[(size_t)J * a.ldp + r0 + lane] = yv;
+            a.Pn[(size_t)I * a.ldp + c0 + lane] = tv;
+            fmac_(Sacc, xI, yv);
+            fmac_(Sacc, xJ, tv);
+        }
+        Sacc = wave_sum(Sacc);
+        if (lane == 0) a.Sn[blockIdx.x] = Sacc;
+    }
+    // ---------------- owners: Z^ partials of the new column over their 64 rows ([V W]^H xh for the columns older than i) ----
+    if (owner) {
+        const int npn = a.np - 1 - i;                  // panel columns older than i: k = c + kk, kk = 0 .. npn-1
+        const int rr = r0 + lane;
+        const T xh = sel(rr < nz, xs[0][lane], zero);
+        const size_t rcl = (size_t)min(rr, max(n - 1, 0));
+        const int nitem = 2 * npn;                     // item = which * npn + kk; a wave takes 16 items per pass
+        for (int g0 = wave * 16; g0 < nitem; g0 += 64) {
+            T wv[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                T tj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int it = g0 + 8 * h + j;
+                    const int itc = min(it, nitem - 1);
+                    const int wh = itc / npn, kk = itc - wh * npn;
+                    const int k = c + kk;
+                    T src = (wh == 0) ? a.A[rcl + (size_t)k * a.lda] : a.W[rcl + (size_t)(k - wbase) * a.ldw];
+                    if (kk == 0) src = (wh == 0) ? vcs[lane] : wcs[lane];   // column c: just finished by this workgroup
+                    T p = zero;
+                    fmac_(p, sel(rr < n && it < nitem, src, zero), xh);
+                    tj[j] = p;
+                }
+                transpose_reduce8_phase1<T>(tj, wv[h][0], wv[h][1]);
+            }
+            const T tval = transpose_reduce_phase2<T>(wv[0][0], wv[0][1], wv[1][0], wv[1][1], lane);
+            if ((lane & 3) == 0) {
+                const int it = g0 + transpose_col_of_lane(lane);
+                if (it < nitem) {
+                    const int wh = it / npn, kk = it - wh * npn;
+                    a.Zpn[(size_t)(I * 2 + wh) * NBMAX + kk] = tval;
+                }
+            }
+        }
+    }
+}
+
 // y = sum of the hemv partials (stand-alone hemv entry point only)
 template <class T> __global__ void __launch_bounds__(256) hemv_gather_kernel(int n, int nt, const T* P, int ldp, T* y) {
     int r = blockIdx.x * 256 + threadIdx.x;
