@@ -109,6 +109,12 @@ constexpr int kTridiagDefault = 1;
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 0;
+// Tridiagonalization: panels whose trailing order is at most this many rows take the one-launch-per-column kernel
+// (panel_col_kernel in trd.hip).  0 = never: measured in round 3, the launch it saves (4.8 us) costs more than that in
+// redundant row work -- 6.7-8.7 us per column in-kernel against 2 x 2.8 (profiles/r03_experiments.txt) -- so the two-kernel
+// form stays the default; option "trd_fuse" / EIGSOLVE_TRD_FUSE selects an order for experiments and the parity tests.
+constexpr int kTrdFuseZ = 0;
+constexpr int kTrdFuseD = 0;
 // Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
 constexpr int kGstModeDefault = 2;
@@ -158,6 +164,7 @@ struct Ctx {
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
+    int trd_fuse = -1;       // >= 0: order below which panels use panel_col_kernel (0 = never); -1 = default per type
     int batch_workers = 3;   // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
                              // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip)
     int trace_marks = 0;     // EIGSOLVE_TRACE_MARKS=1: marker kernels at the phase boundaries (profiling aid, see evd.hip)

@@ -33,11 +33,13 @@ namespace eig {
 #define EIG_TRD_TIMING 0
 #endif
 #if EIG_TRD_TIMING
-__device__ unsigned long long g_trd_stamp[2][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
-__device__ unsigned long long g_trd_count[2];
+__device__ unsigned long long g_trd_stamp[4][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
+__device__ unsigned long long g_trd_count[4];       // kernel 2 / 3: panel_col_kernel, an owner tile (block 0) / an off-diagonal tile (block 1)
+#define CSTAMP(PH) do { if (blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_trd_stamp[2 + blockIdx.x][PH], (unsigned long long)(__builtin_readcyclecounter() - CT0)); } while (0)
 #define TSTAMP(KID, PH, T0) do { if (blockIdx.x == (KID == 0 ? gg : 0) && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
 #else
 #define TSTAMP(KID, PH, T0) do { } while (0)
+#define CSTAMP(PH) do { } while (0)
 #endif
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
@@ -299,11 +301,11 @@ static void launch_row(hipStream_t st, int grid, int nprob, const PanelBatch<T, 
 }
 
 #if EIG_TRD_TIMING
-extern "C" int eigsolve_debug_trd_timing(unsigned long long* out18) {
-    unsigned long long st[2][16], cn[2];
+extern "C" int eigsolve_debug_trd_timing(unsigned long long* out36) {
+    unsigned long long st[4][16], cn[4];
     if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_trd_stamp), sizeof st) != hipSuccess) return -1;
     if (hipMemcpyFromSymbol(cn, HIP_SYMBOL(g_trd_count), sizeof cn) != hipSuccess) return -1;
-    for (int k = 0; k < 2; ++k) { out18[k * 9] = cn[k]; for (int p = 0; p < 8; ++p) out18[k * 9 + 1 + p] = st[k][p]; }
+    for (int k = 0; k < 4; ++k) { out36[k * 9] = cn[k]; for (int p = 0; p < 8; ++p) out36[k * 9 + 1 + p] = st[k][p]; }
     return 0;
 }
 #endif
@@ -568,7 +570,7 @@ template <class T> struct ColArgs {
     T* A; int lda;
     T* W; int ldw;
     int np, nb, i;           // i = column generated by this launch (c = i + 1 is finished by it); FINONLY: i = c - 1
-    double* e; T* tau;
+    double* d; double* e; T* tau;
     // set of the previous launch (describes column c) / set written by this launch (describes column i)
     const T* xprev; T* xnew;
     const T* Pp; T* Pn; int ldp;
@@ -582,9 +584,16 @@ template <class T, int NB> struct ColBatch {
     ColArgs<T> p[NB];
 };
 
+constexpr int CTH = 320;    // panel_col_kernel: four row / tile waves + one scalar wave
+constexpr int ZG = 17;      // Z^ partial blocks per lane without the tail loop (2 halves x 17 >= 33 blocks: order <= 2111)
+
 template <class T, int NB, bool FIRST, bool FINONLY>
-__global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
+__global__ void __launch_bounds__(CTH) panel_col_kernel(ColBatch<T, NB> ab) {
     const ColArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
+#if EIG_TRD_TIMING
+    const long long CT0 = __builtin_readcyclecounter();
+    if (!FIRST && !FINONLY && blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_trd_count[2 + blockIdx.x], 1ULL);
+#endif
     const int i = a.i, c = i + 1;
     const int n = i;                                   // order of the mat-vec: v_i has rows 0 .. i-1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -596,69 +605,59 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
     const int r0 = I * HT, c0 = J * HT;
     const int wbase = a.np - a.nb;
     const int npo = FIRST ? 0 : a.np - 1 - c;          // panel columns older than c
-    const int ntc = (c + HT - 1) / HT;                 // 64-row blocks of the previous launch (order c)
+    const int ntc = c / HT + 1;                        // 64-row blocks of the previous launch (rows 0 .. c)
+    const int nz = n - 1;                              // xh: rows >= nz are zero
 
-    __shared__ T zs[2][2][NBMAX];                      // [which][half][kk] gathered partial sums of Z^
-    __shared__ T z1f[NBMAX + 1], z2f[NBMAX + 1];       // final z1, z2 (wave 0 writes, all read after the barrier)
-    __shared__ T rowW[NBMAX + 1], rowV[NBMAX + 1];
-    __shared__ T s4[4], d4s[4];
-    __shared__ T part[2][4][3][HT];                    // [block sel][sub][psum / acc2 / acc3][row]
+    __shared__ T zs[2][2][NBMAX];                      // [which][half][kk] gathered partial sums of Z^ (raw)
+    __shared__ T rowW[NBMAX + 1], rowV[NBMAX + 1];     // conj of row i of W / V (older columns), [npo] = column c itself
+    __shared__ T s4[4];
+    __shared__ T part[2][4][3][HT];                    // [block sel][sub][psum / Q1 / Q2][row]
     __shared__ T xs[2][HT];                            // raw new column: rows of block I / block J
-    __shared__ T scal[4];                              // scale, tau, alpha (wave 0 -> everybody)
+    __shared__ T scal[4];                              // scale, tau, alpha (scalar wave -> everybody)
     __shared__ T redy[4][HT], redt[HT];
     __shared__ T vcs[HT], wcs[HT];                     // v_c, w_c of the owner's rows (for the Z^ partials)
 
-    // ---------------- tile loads first: they fly during everything below ----------------
-    T av[16];
-    if constexpr (!FINONLY) {
-        const size_t roff = (size_t)min(r0 + lane, max(n - 1, 0));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, max(n - 1, 0)) * a.lda];
-    }
+    // row-work roles of waves 0-3.  Off-diagonal tile: waves 0,1 -> rows of block I, waves 2,3 -> rows of block J, the two
+    // waves of a block split the panel columns / stripes by parity; diagonal tile (and FINONLY): all four on block I.
+    const int bsel = owner ? 0 : ((wave >> 1) & 1);
+    const int nsub = owner ? 4 : 2;
+    const int sub = owner ? (wave & 3) : (wave & 1);
+    const int rb0 = (bsel == 0) ? r0 : c0;
+    const int r = rb0 + lane;
+    const int rows = i + 1;                            // rows 0 .. i of the panel are live
+    const bool active = r < rows;
+    const size_t rc = (size_t)min(r, rows - 1);
 
-    // ---------------- scalars of column c (every workgroup, from the previous launch's partial sums) ----------------
-    T scale = Tr<T>::one(), tau = zero, alpha = zero;
-    if constexpr (!FIRST) {
-        const int ntl = ntc * (ntc + 1) / 2;           // tiles (= S^ partials) of the previous launch
-        // gather: S^ over all threads, D^ / norm partials by every wave (<= 32 + values), Z^ split over the 4 waves
-        T Ssum = zero;
-        for (int q = tid; q < ntl; q += 256) Ssum = Ssum + a.Sp[q];
-        Ssum = wave_sum(Ssum);
-        const int which = wave & 1, half = wave >> 1;
-        T zsum = zero;
-        if (lane < npo)
-            for (int q = half; q < ntc; q += 2) zsum = zsum + a.Zpp[(size_t)(q * 2 + which) * NBMAX + lane];
-        if (lane < npo) zs[which][half][lane] = zsum;
-        if (lane == 0) s4[wave] = Ssum;
-        // row i = c - 1 of the panel (the e_(n-1) part of z, and the row needed for w_i), loaded by wave 0
-        T l_ww = zero, l_wv = zero, l_p = zero;
-        double npv = 0.0;
-        T dv = zero;
-        if (wave == 0) {
+    // =========================== the scalar wave ===========================
+    // larfg scalars of column c, z totals, alpha, w_i: a serial chain (~2500 cycles) that runs beside the row work
+    if (wave == 4) {
+        if constexpr (!FIRST) {
+            T l_ww = zero, l_wv = zero;
             if (lane < npo) {
                 const int k = c + 1 + lane;
                 l_ww = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
                 l_wv = a.A[(size_t)i + (size_t)k * a.lda];
             }
-            for (int q = lane; q < ntc; q += 64) {
-                l_p = l_p + a.Pp[(size_t)q * a.ldp + i];
-                npv += a.NPp[q];
-                dv = dv + a.Dp[q];
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            const double ss = wave_sum(npv);
+            const int ql = min(lane, ntc - 1);
+            T l_p = a.Pp[(size_t)ql * a.ldp + i];
+            double npv = a.NPp[ql];
+            T dv = a.Dp[ql];
             const T alpha_e = *a.alphap;
+            const double aLL = real_(a.A[(size_t)i + (size_t)i * a.lda]);
+            l_p = sel(lane < ntc, l_p, zero); npv = lane < ntc ? npv : 0.0; dv = sel(lane < ntc, dv, zero);
+            for (int q = lane + 64; q < ntc; q += 64) { l_p = l_p + a.Pp[(size_t)q * a.ldp + i]; npv += a.NPp[q]; dv = dv + a.Dp[q]; }
+            if (lane < npo) { rowW[lane] = conj_(l_ww); rowV[lane] = conj_(l_wv); }
+            __syncthreads();                           // #1: Z^ halves and S^ partials are in LDS, rowW / rowV published
+            const double ss = wave_sum(npv);
             double beta;
+            T tau, scale;
             larfg_scalars<T>(ss, alpha_e, beta, tau, scale);
             if (blockIdx.x == 0 && lane == 0) { a.e[c - 1] = beta; a.tau[c - 1] = tau; }
             const T Dsum = wave_sum(dv);
             const T Sraw = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-            const double aLL = real_(a.A[(size_t)i + (size_t)i * a.lda]);
-            // v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
             T cs = zero;
             fmac_(cs, scale, Dsum);
+            // v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
             const double S = abs2_(scale) * real_(Sraw) + 2.0 * real_(cs) + aLL;
             T z1l = zero, z2l = zero;
             if (lane < npo) {
@@ -668,68 +667,152 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
             T t = zero;
             fmac_(t, z1l, z2l);
             const double zz = wave_sum(real_(t));
-            alpha = Tr<T>::make((-0.5 * abs2_(tau)) * (S - 2.0 * zz), 0.0);
-            if constexpr (Tr<T>::cx) {
-                // (v^H A v is real for Hermitian A; the reference form alpha = -1/2 tau (w^H v) reduces to this)
-            }
-            // w_i = W(i, c): row i of the column being finished;  y_i = scale P^(i) + A(i, i)
+            const T alpha = Tr<T>::make((-0.5 * abs2_(tau)) * (S - 2.0 * zz), 0.0);   // (v^H A v is real for Hermitian A)
+            // w_i = W(i, c): row i of the column being finished;  y_i = scale P^(i) + A(i, i),  v_c(i) = 1
             const T yi = scale * wave_sum(l_p) + Tr<T>::make(aLL, 0.0);
             const T u = wave_sum(sel(lane == 0, yi, zero) - (l_ww * z1l + l_wv * z2l));
-            const T wi = tau * u + alpha;              // v_c(i) = 1
-            if (lane < npo) { z1f[lane] = z1l; z2f[lane] = z2l; rowW[lane] = conj_(l_ww); rowV[lane] = conj_(l_wv); }
+            const T wi = tau * u + alpha;
             if (lane == 0) { rowW[npo] = conj_(wi); rowV[npo] = Tr<T>::one(); scal[0] = scale; scal[1] = tau; scal[2] = alpha; }
+        } else {
+            __syncthreads();                           // #1
         }
-        __syncthreads();
-        scale = scal[0]; tau = scal[1]; alpha = scal[2];
+        __syncthreads();                               // #2: scalars published, row-work partial sums published
+        if constexpr (FINONLY) return;
+        __syncthreads();                               // #3: xs published
+        __syncthreads();                               // #4: tile partial sums published
+        // finish the tile: raw partials of the new column
+        const T yv = (redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane]);
+        const T tv = redt[lane];
+        const T xI = sel(r0 + lane < nz, xs[0][lane], zero);
+        const T xJ = sel(c0 + lane < nz, xs[1][lane], zero);
+        T Sacc = zero;
+        if (owner) {
+            const T sm = yv + tv;
+            a.Pn[(size_t)J * a.ldp + r0 + lane] = sm;
+            fmac_(Sacc, xI, sm);
+        } else {
+            a.Pn[(size_t)J * a.ldp + r0 + lane] = yv;
+            a.Pn[(size_t)I * a.ldp + c0 + lane] = tv;
+            fmac_(Sacc, xI, yv);
+            fmac_(Sacc, xJ, tv);
+        }
+        Sacc = wave_sum(Sacc);
+        if (lane == 0) a.Sn[blockIdx.x] = Sacc;
+        if (!FIRST) CSTAMP(6);
+        return;
     }
 
-    // ---------------- row work: x_I (and x_J), finishing W(:, c) for those rows ----------------
-    // off-diagonal tile: waves 0,1 -> rows of block I, waves 2,3 -> rows of block J, the two waves of a block split the
-    // panel columns / stripes by parity; diagonal tile (and FINONLY): all four waves on block I, split four ways.
-    const int bsel = owner ? 0 : (wave >> 1);
-    const int nsub = owner ? 4 : 2;
-    const int sub = owner ? wave : (wave & 1);
-    const int rb0 = (bsel == 0) ? r0 : c0;
-    const int r = rb0 + lane;
-    const int rows = i + 1;                            // rows 0 .. i of the panel are live
-    const bool active = r < rows;
-    const size_t rc = (size_t)min(r, rows - 1);
+    // =========================== waves 0-3 ===========================
+    // ---- every load that depends on nothing: the tile, the gather of Z^ / S^, the first row-work loads ----
+    T av[16];
+    if constexpr (!FINONLY) {
+        const size_t roff = (size_t)min(r0 + lane, max(n - 1, 0));
+#pragma unroll
+        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, max(n - 1, 0)) * a.lda];
+    }
     T xr_new = zero, wr = zero, vr = zero;
     if constexpr (FIRST) {
         T acur = a.A[rc + (size_t)i * a.lda];
         if (r == i) acur = Tr<T>::realpart(acur);
         xr_new = sel(active, acur, zero);
+        __syncthreads();                               // #1
+        __syncthreads();                               // #2
     } else {
-        T psum = zero, acc2 = zero, acc3 = zero;
-        for (int q = sub; q < ntc; q += nsub) psum = psum + a.Pp[(size_t)q * a.ldp + rc];
-#pragma unroll 4
-        for (int kk = sub; kk < npo; kk += nsub) {
-            const int k = c + 1 + kk;
-            const T vv = a.A[rc + (size_t)k * a.lda];
-            const T wv = a.W[rc + (size_t)(k - wbase) * a.ldw];
-            acc2 = acc2 - (wv * z1f[kk] + vv * z2f[kk]);
-            if constexpr (!FINONLY) acc3 = acc3 + (vv * rowW[kk] + wv * rowV[kk]);
+        {
+            // gather: Z^ (lane = panel column, waves = which x half of the blocks), S^ (all threads of waves 0-3)
+            const int which = wave & 1, half = wave >> 1;
+            const int kz = min(lane, max(npo - 1, 0));
+            T zt[ZG];
+#pragma unroll
+            for (int u = 0; u < ZG; ++u) zt[u] = a.Zpp[(size_t)(min(half + 2 * u, ntc - 1) * 2 + which) * NBMAX + kz];
+            const int ntl = ntc * (ntc + 1) / 2;
+            T st[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) st[u] = a.Sp[min(tid + 256 * u, ntl - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+            T zsum = zero, Ssum = zero;
+#pragma unroll
+            for (int u = 0; u < ZG; ++u) zsum = zsum + sel(half + 2 * u < ntc, zt[u], zero);
+            for (int q = half + 2 * ZG; q < ntc; q += 2) zsum = zsum + a.Zpp[(size_t)(q * 2 + which) * NBMAX + kz];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) Ssum = Ssum + sel(tid + 256 * u < ntl, st[u], zero);
+            for (int q = tid + 768; q < ntl; q += 256) Ssum = Ssum + a.Sp[q];
+            if (lane < npo) zs[which][half][lane] = zsum;
+            Ssum = wave_sum(Ssum);
+            if (lane == 0) s4[wave] = Ssum;
+        }
+        if (!FINONLY) CSTAMP(0);
+        __syncthreads();                               // #1
+        if (!FINONLY) CSTAMP(1);
+        // ---- row sums that need no scalar:  psum = sum of P^ stripes,  Q1 = sum W z1^ + V z2^,  Q2 = sum V conj(W(i,:)) + W conj(V(i,:))
+        //      (y = scale psum + A(:, i);  w = tau (y - scale Q1 - Q2) + alpha v_c;  column update = Q2 + v_c conj(w_i) + w) ----
+        constexpr int KB = Tr<T>::cx ? 4 : 8;          // panel columns per load batch (two batches in flight)
+        T psum = zero, q1 = zero, q2 = zero;
+        {
+            T pt[ZG];
+#pragma unroll
+            for (int u = 0; u < ZG; ++u) {
+                const int q = sub + nsub * u;
+                pt[u] = (u * nsub < 2 * ZG) ? a.Pp[(size_t)min(q, ntc - 1) * a.ldp + rc] : zero;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < ZG; ++u) psum = psum + sel(sub + nsub * u < ntc && u * nsub < 2 * ZG, pt[u], zero);
+            for (int q = sub + nsub * ZG; q < ntc; q += nsub) psum = psum + a.Pp[(size_t)q * a.ldp + rc];
+        }
+        {
+            T vb[2][KB], wb[2][KB];
+            const int nmine = (npo - sub + nsub - 1) / nsub;       // my panel columns: kk = sub + nsub * m
+            auto issue = [&](int buf, int m0) {
+#pragma unroll
+                for (int m = 0; m < KB; ++m) {
+                    const int kk = min(sub + nsub * (m0 + m), max(npo - 1, 0));
+                    const int k = c + 1 + kk;
+                    vb[buf][m] = a.A[rc + (size_t)k * a.lda];
+                    wb[buf][m] = a.W[rc + (size_t)(k - wbase) * a.ldw];
+                }
+            };
+            auto consume = [&](int buf, int m0) {
+#pragma unroll
+                for (int m = 0; m < KB; ++m) {
+                    const int kk = sub + nsub * (m0 + m);
+                    if (m0 + m < nmine) {
+                        const T z1r = zs[0][0][kk] + zs[0][1][kk], z2r = zs[1][0][kk] + zs[1][1][kk];
+                        q1 = q1 + (wb[buf][m] * z1r + vb[buf][m] * z2r);
+                        q2 = q2 + (vb[buf][m] * rowW[kk] + wb[buf][m] * rowV[kk]);
+                    }
+                }
+            };
+            if (nmine > 0) issue(0, 0);
+            for (int m0 = 0; m0 < nmine; m0 += 2 * KB) {
+                if (m0 + KB < nmine) issue(1, m0 + KB);
+                consume(0, m0);
+                if (m0 + 2 * KB < nmine) issue(0, m0 + 2 * KB);
+                if (m0 + KB < nmine) consume(1, m0 + KB);
+            }
         }
         part[bsel][sub][0][lane] = psum;
-        part[bsel][sub][1][lane] = acc2;
-        part[bsel][sub][2][lane] = acc3;
+        part[bsel][sub][1][lane] = q1;
+        part[bsel][sub][2][lane] = q2;
         const T xc_raw = a.xprev[rc];
         T acur = a.A[rc + (size_t)i * a.lda];          // column i: A(r, n_c - 1) for y AND the column to update
         if (r == i) acur = Tr<T>::realpart(acur);
-        __syncthreads();
+        __syncthreads();                               // #2
+        if (!FINONLY) CSTAMP(3);
+        const T scale = scal[0], tau = scal[1], alpha = scal[2];
         T ps = part[bsel][0][0][lane] + part[bsel][1][0][lane];
-        T a2 = part[bsel][0][1][lane] + part[bsel][1][1][lane];
-        T a3 = part[bsel][0][2][lane] + part[bsel][1][2][lane];
+        T a1 = part[bsel][0][1][lane] + part[bsel][1][1][lane];
+        T a2 = part[bsel][0][2][lane] + part[bsel][1][2][lane];
         if (owner) {
             ps = ps + (part[0][2][0][lane] + part[0][3][0][lane]);
-            a2 = a2 + (part[0][2][1][lane] + part[0][3][1][lane]);
-            a3 = a3 + (part[0][2][2][lane] + part[0][3][2][lane]);
+            a1 = a1 + (part[0][2][1][lane] + part[0][3][1][lane]);
+            a2 = a2 + (part[0][2][2][lane] + part[0][3][2][lane]);
         }
         vr = (r < c - 1) ? scale * xc_raw : ((r == c - 1) ? Tr<T>::one() : zero);
         const T y = scale * ps + acur;
-        wr = tau * (y + a2) + alpha * vr;
+        wr = tau * (y - scale * a1 - a2) + alpha * vr;
         if constexpr (!FINONLY) {
-            const T upd = a3 + (vr * rowW[npo] + wr * rowV[npo]);
+            const T upd = a2 + (vr * rowW[npo] + wr * rowV[npo]);
             T anew = acur - upd;
             if (r == i) anew = Tr<T>::realpart(anew);
             xr_new = sel(active, anew, zero);
@@ -742,7 +825,6 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
     if constexpr (FINONLY) return;
 
     // ---------------- publish the raw new column (LDS for this tile, global by the owners) ----------------
-    const int nz = n - 1;                              // xh: rows >= nz are zero
     if (owner) {
         if (wave == 0) { xs[0][lane] = xr_new; xs[1][lane] = xr_new; vcs[lane] = vr; wcs[lane] = wr; }
     } else if ((wave & 1) == 0) {
@@ -752,6 +834,7 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
         if (active) {
             a.xnew[r] = xr_new;
             if (r == i - 1) *a.alphan = xr_new;
+            if (r == i) a.d[i] = real_(xr_new);        // (A(i,i) itself stays as it is: every workgroup of this launch reads it)
         }
         const T alast = a.A[(size_t)min(r, max(n - 1, 0)) + (size_t)max(n - 1, 0) * a.lda];   // A(r, n-1), used for r < nz
         double nrm = (active && r <= i - 2) ? abs2_(xr_new) : 0.0;
@@ -761,7 +844,8 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
         dd = wave_sum(dd);
         if (lane == 0) { a.NPn[I] = nrm; a.Dn[I] = dd; }
     }
-    __syncthreads();
+    __syncthreads();                                   // #3
+    if (!FIRST) CSTAMP(4);
 
     // ---------------- the tile: y_I += A_IJ xh_J,  y_J += A_IJ^H xh_I  (as panel_mv_kernel, raw xh) ----------------
     {
@@ -803,34 +887,26 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
         redy[wave][lane] = yI;
         if ((lane & 3) == 0) redt[wave * 16 + transpose_col_of_lane(lane)] = tval;
     }
-    __syncthreads();
-    if (wave == 0) {
-        const T yv = (redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane]);
-        const T tv = redt[lane];
-        const T xI = sel(r0 + lane < nz, xs[0][lane], zero);
-        const T xJ = sel(c0 + lane < nz, xs[1][lane], zero);
-        T Sacc = zero;
-        if (owner) {
-            const T sm = yv + tv;
-            a.Pn[(size_t)J * a.ldp + r0 + lane] = sm;
-            fmac_(Sacc, xI, sm);
-        } else {
-            a.Pn[(size_t)J * a.ldp + r0 + lane] = yv;
-            a.Pn[(size_t)I * a.ldp + c0 + lane] = tv;
-            fmac_(Sacc, xI, yv);
-            fmac_(Sacc, xJ, tv);
-        }
-        Sacc = wave_sum(Sacc);
-        if (lane == 0) a.Sn[blockIdx.x] = Sacc;
-    }
+    __syncthreads();                                   // #4 (the scalar wave finishes the tile)
+    if (!FIRST) CSTAMP(5);
     // ---------------- owners: Z^ partials of the new column over their 64 rows ([V W]^H xh for the columns older than i) ----
     if (owner) {
         const int npn = a.np - 1 - i;                  // panel columns older than i: k = c + kk, kk = 0 .. npn-1
         const int rr = r0 + lane;
         const T xh = sel(rr < nz, xs[0][lane], zero);
         const size_t rcl = (size_t)min(rr, max(n - 1, 0));
-        const int nitem = 2 * npn;                     // item = which * npn + kk; a wave takes 16 items per pass
+        const int nitem = 2 * npn;                     // items: [V columns kk = 0 .. npn-1 | W columns]; 16 per wave and pass
         for (int g0 = wave * 16; g0 < nitem; g0 += 64) {
+            T src[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int it = min(g0 + j, nitem - 1);
+                const bool isw = it >= npn;
+                const int kk = isw ? it - npn : it;
+                const T* base = isw ? a.W + (size_t)(c + kk - wbase) * a.ldw : a.A + (size_t)(c + kk) * a.lda;
+                src[j] = base[rcl];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             T wv[2][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -838,13 +914,11 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int it = g0 + 8 * h + j;
-                    const int itc = min(it, nitem - 1);
-                    const int wh = itc / npn, kk = itc - wh * npn;
-                    const int k = c + kk;
-                    T src = (wh == 0) ? a.A[rcl + (size_t)k * a.lda] : a.W[rcl + (size_t)(k - wbase) * a.ldw];
-                    if (kk == 0) src = (wh == 0) ? vcs[lane] : wcs[lane];   // column c: just finished by this workgroup
+                    T sv = src[8 * h + j];
+                    if (it == 0) sv = vcs[lane];                 // column c itself: just finished by this workgroup
+                    if (it == npn) sv = wcs[lane];
                     T p = zero;
-                    fmac_(p, sel(rr < n && it < nitem, src, zero), xh);
+                    fmac_(p, sel(rr < n && it < nitem, sv, zero), xh);
                     tj[j] = p;
                 }
                 transpose_reduce8_phase1<T>(tj, wv[h][0], wv[h][1]);
@@ -853,12 +927,13 @@ __global__ void __launch_bounds__(256) panel_col_kernel(ColBatch<T, NB> ab) {
             if ((lane & 3) == 0) {
                 const int it = g0 + transpose_col_of_lane(lane);
                 if (it < nitem) {
-                    const int wh = it / npn, kk = it - wh * npn;
-                    a.Zpn[(size_t)(I * 2 + wh) * NBMAX + kk] = tval;
+                    const bool isw = it >= npn;
+                    a.Zpn[(size_t)(I * 2 + (isw ? 1 : 0)) * NBMAX + (isw ? it - npn : it)] = tval;
                 }
             }
         }
     }
+    if (!FIRST) CSTAMP(7);
 }
 
 // y = sum of the hemv partials (stand-alone hemv entry point only)
@@ -1003,10 +1078,41 @@ template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N, int prob = 0)
     return s;
 }
 
+// double-buffered partial-sum sets of the one-launch-per-column path (panel_col_kernel), sized for order nmax
+template <class T> struct ColScratch {
+    T* x[2]; T* P[2]; T* S[2]; T* D[2]; T* Zp[2]; T* alpha[2];
+    double* NP[2];
+    int ldp;
+};
+template <class T> static ColScratch<T> col_scratch(Ctx& c, int nmax, int prob = 0) {
+    ColScratch<T> s;
+    const int nt = nmax / HT + 1;
+    s.ldp = nt * HT;
+    const size_t per = (size_t)(nt * HT + 64) + (size_t)nt * s.ldp + (size_t)(nt * (nt + 1) / 2 + 64) + (size_t)(nt + 64) +
+                       (size_t)(nt + 1) * 2 * NBMAX + 8;
+    char nm[32];
+    snprintf(nm, sizeof nm, prob == 0 ? "trd_col" : "trd_col#%d", prob);
+    T* base = c.scratch<T>(nm, 2 * per);
+    snprintf(nm, sizeof nm, prob == 0 ? "trd_colNP" : "trd_colNP#%d", prob);
+    double* np = c.scratch<double>(nm, 2 * (size_t)(nt + 64));
+    for (int b = 0; b < 2; ++b) {
+        T* q = base + (size_t)b * per;
+        s.x[b] = q; q += nt * HT + 64;
+        s.P[b] = q; q += (size_t)nt * s.ldp;
+        s.S[b] = q; q += nt * (nt + 1) / 2 + 64;
+        s.D[b] = q; q += nt + 64;
+        s.Zp[b] = q; q += (size_t)(nt + 1) * 2 * NBMAX;
+        s.alpha[b] = q;
+        s.NP[b] = np + (size_t)b * (nt + 64);
+    }
+    return s;
+}
+
 // one problem of a lockstep batch: its matrix, outputs, panel workspace and private scratch
 template <class T> struct TrdProb {
     T* A; double* d; double* e; T* tau; T* W;
     TrdScratch<T> sc;
+    ColScratch<T> cs;
 };
 
 template <class T, int NB>
@@ -1049,8 +1155,52 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
     EIG_HIP(hipGetLastError());
 }
 
+// One panel through panel_col_kernel: nb launches (one per column) + the finish-only launch for the panel's leftmost column.
+template <class T, int NB>
+static void latrd_panel_fused(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr, int np, int nb, int lda, int ldw,
+                              bool sweep_only = false, long* nlaunch = nullptr, double* algo_bytes = nullptr) {
+    ColBatch<T, NB> ab;
+    auto fill = [&](int i) {
+        for (int q = 0; q < NB; ++q) {
+            const TrdProb<T>& P = pr[q < nprob ? q : 0];
+            ColArgs<T>& a = ab.p[q];
+            const int nw = i & 1, pv = (i + 1) & 1;       // set written by this launch / set of the previous launch
+            a.A = P.A; a.lda = lda; a.W = P.W; a.ldw = ldw; a.np = np; a.nb = nb; a.i = i; a.d = P.d; a.e = P.e; a.tau = P.tau;
+            a.xprev = P.cs.x[pv]; a.xnew = P.cs.x[nw];
+            a.Pp = P.cs.P[pv]; a.Pn = P.cs.P[nw]; a.ldp = P.cs.ldp;
+            a.Sp = P.cs.S[pv]; a.Sn = P.cs.S[nw];
+            a.Dp = P.cs.D[pv]; a.Dn = P.cs.D[nw];
+            a.NPp = P.cs.NP[pv]; a.NPn = P.cs.NP[nw];
+            a.Zpp = P.cs.Zp[pv]; a.Zpn = P.cs.Zp[nw];
+            a.alphap = P.cs.alpha[pv]; a.alphan = P.cs.alpha[nw];
+        }
+    };
+    for (int i = np - 1; i >= np - nb; --i) {
+        fill(i);
+        const int nt = i / HT + 1;                   // tiles over rows 0 .. i (row i has an owner even when i % 64 == 0)
+        const dim3 grid(nt * (nt + 1) / 2, nprob);
+        if (i == np - 1) hipLaunchKernelGGL((panel_col_kernel<T, NB, true, false>), grid, dim3(CTH), 0, st, ab);
+        else hipLaunchKernelGGL((panel_col_kernel<T, NB, false, false>), grid, dim3(CTH), 0, st, ab);
+        if (nlaunch) ++*nlaunch;
+        if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)i * (double)(i + 1) * 0.5;
+    }
+    if (!sweep_only) {
+        const int cfin = np - nb;                    // the panel's leftmost column: finished, nothing generated
+        fill(cfin - 1);
+        const int ntc = (cfin + HT - 1) / HT;
+        hipLaunchKernelGGL((panel_col_kernel<T, NB, false, true>), dim3(ntc, nprob), dim3(CTH), 0, st, ab);
+    }
+    EIG_HIP(hipGetLastError());
+}
+
 // nprob problems of order N reduced in lockstep: every per-column launch carries all of them (blockIdx.y); the trailing
 // rank-2nb updates and the final 32x32 blocks are launched per problem.  nprob = 1 is the plain zhetrd_gpu path.
+// panels whose trailing order is <= this go through panel_col_kernel (one launch per column); option "trd_fuse"
+template <class T> static int trd_fuse_order(const Ctx& c) {
+    if (c.trd_fuse >= 0) return c.trd_fuse;
+    return Tr<T>::cx ? kTrdFuseZ : kTrdFuseD;
+}
+
 template <class T, int NB>
 static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdProb<T>* pr, int lda, int nb) {
     if (N <= 0) return;
@@ -1062,22 +1212,33 @@ static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdPr
         for (int q = 0; q < nprob; ++q)
             her2k_un<T>(c, st, npn - nbn, nbn, pr[q].A + (size_t)(npn - nbn) * lda, lda, pr[q].W, ldw, pr[q].A, lda);
     };
+    const int fuse_n = trd_fuse_order<T>(c);
+    int fused_from = 0;                               // columns below this were reduced by panel_col_kernel, which stores d itself
+    auto panel = [&](int npn, int nbn) {
+        if (npn <= fuse_n) {
+            if (fused_from == 0) fused_from = npn;
+            latrd_panel_fused<T, NB>(c, st, nprob, pr, npn, nbn, lda, ldw);
+        } else {
+            latrd_panel<T, NB>(c, st, nprob, pr, npn, nbn, lda, ldw);
+        }
+    };
     while (np - nb >= nx) {  // zhetrd_gpu.F90:60-71
-        latrd_panel<T, NB>(c, st, nprob, pr, np, nb, lda, ldw);
+        panel(np, nb);
         trailing(np, nb);
         np -= nb;
     }
     int nbr = np - nx;  // remainder panel, :73-83
     if (nbr > 0) {
-        latrd_panel<T, NB>(c, st, nprob, pr, np, nbr, lda, ldw);
+        panel(np, nbr);
         trailing(np, nbr);
         np = nx;
     }
     int n0 = N < nx ? N : nx;
     for (int q = 0; q < nprob; ++q) {
         hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);
-        if (N > n0)
-            hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - n0 + 255) / 256), dim3(256), 0, st, n0, N, (const T*)pr[q].A, lda,
+        const int x0 = fused_from > n0 ? fused_from : n0;
+        if (N > x0)
+            hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - x0 + 255) / 256), dim3(256), 0, st, x0, N, (const T*)pr[q].A, lda,
                                pr[q].d);
     }
     EIG_HIP(hipGetLastError());
@@ -1086,7 +1247,7 @@ static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdPr
 template <class T>
 void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb) {
     if (N <= 0) return;
-    TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N)};
+    TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N), col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)))};
     hetrd_lockstep<T, 1>(c, st, N, 1, &pr, lda, nb);
 }
 
@@ -1098,7 +1259,9 @@ void hetrd_upper_batch(Ctx& c, hipStream_t st, int N, int nprob, T* const* A, in
     for (int q0 = 0; q0 < nprob; q0 += MAXB) {
         const int nq = nprob - q0 < MAXB ? nprob - q0 : MAXB;
         TrdProb<T> pr[MAXB];
-        for (int q = 0; q < nq; ++q) pr[q] = TrdProb<T>{A[q0 + q], d[q0 + q], e[q0 + q], tau[q0 + q], W[q0 + q], trd_scratch<T>(c, N, q)};
+        for (int q = 0; q < nq; ++q)
+            pr[q] = TrdProb<T>{A[q0 + q], d[q0 + q], e[q0 + q], tau[q0 + q], W[q0 + q], trd_scratch<T>(c, N, q),
+                               col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)), q)};
         if (nq == 1) hetrd_lockstep<T, 1>(c, st, N, 1, pr, lda, nb);
         else hetrd_lockstep<T, MAXB>(c, st, N, nq, pr, lda, nb);
     }
@@ -1120,13 +1283,20 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     *nlaunch = 0; *algo_bytes = 0.0;
     const int nx = TD;
     int np = N;
-    TrdProb<T> pr{A, nullptr, e, tau, W, sc};
+    double* dsink = c.scratch<double>("sweep_d", (size_t)N + 8);
+    TrdProb<T> pr{A, dsink, e, tau, W, sc, col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)))};
+    const int fuse_n = trd_fuse_order<T>(c);
+    auto panel = [&](int npn, int nbn) {
+        // (below the fuse order the mat-vec IS the one-launch-per-column kernel: row work + tile, as the reduction runs it)
+        if (npn <= fuse_n) latrd_panel_fused<T, 1>(c, st, 1, &pr, npn, nbn, lda, N, true, nlaunch, algo_bytes);
+        else latrd_panel<T, 1>(c, st, 1, &pr, npn, nbn, lda, N, true, nlaunch, algo_bytes);
+    };
     while (np - nb >= nx) {
-        latrd_panel<T, 1>(c, st, 1, &pr, np, nb, lda, N, true, nlaunch, algo_bytes);
+        panel(np, nb);
         np -= nb;
     }
     int nbr = np - nx;
-    if (nbr > 0) latrd_panel<T, 1>(c, st, 1, &pr, np, nbr, lda, N, true, nlaunch, algo_bytes);
+    if (nbr > 0) panel(np, nbr);
 }
 
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather) {

@@ -318,6 +318,35 @@ def test_hetrd_vs_oracle(env, cplx, n, nb, fam):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,fuse", [(200, 4096), (411, 4096), (700, 300), (129, 64)])
+def test_hetrd_one_launch_per_column_path(env, cplx, n, fuse):
+    """Option trd_fuse: panels of trailing order <= fuse go through panel_col_kernel (row work folded into the mat-vec launch,
+    larfg scalars applied one launch later by linearity; off by default, measured slower).  d, e, tau and the reflectors must
+    agree with the oracle like the default path's, incl. orders where a column index is a multiple of 64 (ownerless row) and
+    the switch from the two-kernel path inside one reduction (n = 700, fuse = 300)."""
+    torch, oracle, api = env
+    A = oracle.gen_spd(n, 5000 + n, cplx) if n < 200 else oracle.gen_spd_fast(n, 5000 + n, cplx)
+    Ao, do, eo, tauo = oracle.hetrd(np.triu(A), nb=32)
+    Ad = api.to_device(np.triu(A))
+    try:
+        assert api.set_option("trd_fuse", fuse) == 0
+        d, e, tau = api.hetrd(Ad)
+    finally:
+        api.set_option("trd_fuse", -1)
+    d, e = d.cpu().numpy(), e.cpu().numpy()
+    scale = np.abs(A).max()
+    tol = 200 * n * EPS * scale
+    assert np.abs(d - do).max() <= tol and np.abs(np.abs(e) - np.abs(eo)).max() <= tol
+    # eigenvalues of the tridiagonal matrix = eigenvalues of A
+    import scipy.linalg as sl
+    wt = sl.eigvalsh_tridiagonal(d, e)
+    wa = np.linalg.eigvalsh(A)
+    assert np.abs(wt - wa).max() <= 200 * n * EPS * np.abs(wa).max()
+    Ah = api.to_host(Ad)
+    assert np.array_equal(np.tril(Ah, -1), np.zeros_like(np.tril(Ah, -1)))      # nothing written below the diagonal
+
+
+@pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n", [40, 130, 300])
 def test_hetrd_reconstruction(env, cplx, n):
     """Backward check independent of any other implementation: Q^H A Q = T (Q = H_{n-2}...H_0) rebuilt from

@@ -13,19 +13,20 @@ def run(n, cx=True):
     A = rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cx else 0)
     A = A + A.conj().T
     lib = api.lib()
-    out0 = (ctypes.c_ulonglong * 18)()
+    out0 = (ctypes.c_ulonglong * 36)()
     lib.eigsolve_debug_trd_timing(out0)
     Ad = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()
     r = api.hetrd(Ad)
     torch.cuda.synchronize()
-    out1 = (ctypes.c_ulonglong * 18)()
+    out1 = (ctypes.c_ulonglong * 36)()
     lib.eigsolve_debug_trd_timing(out1)
-    d = [out1[i] - out0[i] for i in range(18)]
-    for k, name in ((0, "mv "), (1, "row")):
+    d = [out1[i] - out0[i] for i in range(36)]
+    for k, name in ((0, "mv "), (1, "row"), (2, "col owner"), (3, "col offdiag")):
         cnt = d[k * 9]
-        ph = [d[k * 9 + 1 + p] / max(cnt, 1) for p in range(6)]
+        ph = [d[k * 9 + 1 + p] / max(cnt, 1) for p in range(8)]
         print("n=%5d %s launches=%5d  cumulative cycles at stamps: %s" % (n, name, cnt, " ".join("%7.0f" % x for x in ph)))
 
 for n in (256, 1024, 4096):
     run(n)
 run(1024, cx=False)
+run(2048, cx=False)
