@@ -57,13 +57,13 @@ struct Epi {
 };
 
 // Strided batch descriptor: entry zb = 0..count-1 uses A.p + zb*sA, Bt.p + zb*sB, C + zb*sC, mask offsets + zb*dMoff*,
-// K + zb*dK, and M, N clipped to cap* - zb*dcap (INT_MAX = no clipping).  `splits` is filled in by gemm_batched.
+// K + zb*dK, and M, N, K clipped to cap* - zb*dcap (INT_MAX = no clipping).  `splits` is filled in by gemm_batched.
 struct GemmBatch {
     int count = 0;
     int splits = 1;
     long sA = 0, sB = 0, sC = 0;
     int dMoffA = 0, dMoffB = 0, dK = 0;
-    int capM = INT_MAX, capN = INT_MAX, dcap = 0;
+    int capM = INT_MAX, capN = INT_MAX, capK = INT_MAX, dcap = 0;
 };
 
 // C(MxN) = alpha * A * B + beta * C.

@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
         g.A.p += (long)zb * g.bt.sA; g.B.p += (long)zb * g.bt.sB; g.C += (long)zb * g.bt.sC;
         g.A.moff += zb * g.bt.dMoffA; g.B.moff += zb * g.bt.dMoffB;
         g.K += zb * g.bt.dK;
+        if (g.bt.capK != INT_MAX) g.K = min(g.K, g.bt.capK - zb * g.bt.dcap);
         g.M = min(g.M, g.bt.capM - zb * g.bt.dcap);
         g.N = min(g.N, g.bt.capN - zb * g.bt.dcap);
     }
@@ -1233,7 +1234,9 @@ template <class T> __global__ void __launch_bounds__(256) tri_merge_kernel(int s
         if (q < cw) G[(size_t)(r0 + r) + (size_t)(c0 + pc * 32 + cb + q) * BB] = -acc[q];
 }
 
-// groups g0 .. g0+ng-1 (their 64-block inverses must be complete)
+// groups g0 .. g0+ng-1 (their 64-block inverses must be complete).  The merges P = -L M R are two strided-batch MFMA products
+// per off-diagonal block position (X = M R, P = -L X over all groups at once): 6 small launches, ~50 us for N = 4096, where
+// the round-1 one-lane-per-row kernel (tri_merge_kernel, kept for reference) took 2 x 150 us.
 template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N, const T* U, int ldu, int g0, int ng) {
     const int nblk64 = (N + DB - 1) / DB, ngall = (N + BB - 1) / BB;
     if (ng <= 0) return;
@@ -1241,9 +1244,37 @@ template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N
     T* inv256 = c.scratch<T>("invU256", (size_t)ngall * BB * BB);
     EIG_HIP(hipMemsetAsync(inv256 + (size_t)g0 * BB * BB, 0, sizeof(T) * (size_t)ng * BB * BB, st));
     hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256, g0);
-    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N, g0);
-    hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N, g0);
     EIG_HIP(hipGetLastError());
+    static const bool old_merge = getenv("EIGSOLVE_TRI_MERGE_OLD") != nullptr;
+    if (old_merge) {
+        hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N, g0);
+        hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N, g0);
+        EIG_HIP(hipGetLastError());
+        return;
+    }
+    T* X = c.scratch<T>("inv_X", (size_t)ngall * 128 * 128);
+    T* G0 = inv256 + (size_t)g0 * BB * BB;
+    const size_t k00 = (size_t)g0 * BB;
+    auto merge = [&](int s_, int r0) {
+        const int c0 = r0 + s_;
+        EIG_HIP(hipMemsetAsync(X, 0, sizeof(T) * (size_t)ng * s_ * s_, st));     // rows clipped at the matrix end stay zero
+        GemmBatch b1;                                                              // X = M R
+        b1.count = ng; b1.sA = (long)BB * (ldu + 1); b1.sB = (long)BB * BB; b1.sC = (long)s_ * s_; b1.dcap = BB;
+        b1.capM = N - (int)k00 - r0; b1.capK = N - (int)k00 - c0;
+        Operand<T> M = opA('N', U + (k00 + r0) + (k00 + c0) * (size_t)ldu, ldu);
+        Operand<T> R = op_plain((const T*)(G0 + (size_t)c0 * (1 + BB)), BB, 1, 0);
+        R.mask = M_UPPER;
+        gemm_batched<T>(c, st, s_, s_, s_, Tr<T>::one(), M, R, Tr<T>::zero(), X, s_, Epi(), b1);
+        GemmBatch b2;                                                              // P = -L X
+        b2.count = ng; b2.sA = (long)BB * BB; b2.sB = (long)s_ * s_; b2.sC = (long)BB * BB;
+        Operand<T> L = op_plain((const T*)(G0 + (size_t)r0 * (1 + BB)), BB, 0, 0);
+        L.mask = M_UPPER;
+        gemm_batched<T>(c, st, s_, s_, s_, Tr<T>::make(-1.0, 0.0), L, opB('N', (const T*)X, s_), Tr<T>::zero(),
+                        G0 + (size_t)r0 + (size_t)c0 * BB, BB, Epi(), b2);
+    };
+    merge(64, 0);
+    merge(64, 128);
+    merge(128, 0);
 }
 template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
     build_inv256_groups(c, st, N, U, ldu, 0, (N + BB - 1) / BB);

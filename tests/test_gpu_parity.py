@@ -334,7 +334,7 @@ def test_hetrd_one_launch_per_column_path(env, cplx, n, fuse):
     finally:
         api.set_option("trd_fuse", -1)
     d, e = d.cpu().numpy(), e.cpu().numpy()
-    scale = np.abs(A).max()
+    scale = np.linalg.norm(A, 2)                 # backward-error scale, as in test_hetrd_vs_oracle
     tol = 200 * n * EPS * scale
     assert np.abs(d - do).max() <= tol and np.abs(np.abs(e) - np.abs(eo)).max() <= tol
     # eigenvalues of the tridiagonal matrix = eigenvalues of A
