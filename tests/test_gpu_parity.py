@@ -870,7 +870,7 @@ def _report(name, obj):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    path = os.path.join(d, "r02_parity_full_size.json")
+    path = os.path.join(d, "r03_parity_full_size.json")
     cur = {}
     if os.path.exists(path):
         try:
@@ -1016,6 +1016,44 @@ def test_c5_zhegvdx_n2048_m512(env, golden_dir, fam):
         assert res <= max(n * EPS, 4 * lap_res), (res, lap_res)
         assert bortho <= max(1e-10, 10 * lap_bo), (bortho, lap_bo)
         assert l2w <= 1e-8      # the 512 lowest eigenvalues are insensitive to the factor's rounding
+
+
+def test_c5_full_size_batch_all_64_problems(env, golden_dir):
+    """configs[4] at FULL size through the path bench.py runs by default: 64 distinct zhegvdx N=2048 eigenpairs 1..512 problems
+    (bench.py's generator and seeds, shifted B for the strict gate), handed to eigsolve_zhegvdx_batch 8 at a time from this one
+    thread (library workers).  EVERY problem is checked on the device: residual <= N eps, B-orthonormality, eigenvalues
+    ascending; problem 0 additionally against a one-problem solve (bit-identical) and, through the generalized trace identity
+    sum(w_all) = trace(B^-1 A), against an independent quantity.  Size-independent properties at BASELINE's full batch size."""
+    torch, oracle, api = env
+    import bench
+    n, m, NP, F = 2048, 512, 64, 8
+    dev = torch.device("cuda", 0)
+    wss = [api.Workspace(n, True) for _ in range(F)]
+    worst = {"residual": 0.0, "b_orthonormality": 0.0}
+    w0 = None
+    for g0 in range(0, NP, F):
+        prist = [bench.gen_pair(n, True, bench.problem_seed(4, p, 0), dev, shift_b=float(n)) for p in range(g0, g0 + F)]
+        work = [(a.clone(), b.clone()) for a, b in prist]
+        infos = api.hegvdx_batch(work, 1, m, wss)
+        assert infos == [0] * F
+        for q in range(F):
+            A0, B0 = prist[q]
+            wv = wss[q].w[:m]
+            assert bool((wv[1:] >= wv[:-1]).all()), g0 + q
+            res, berr, bo = bench.check_solution(torch, A0, B0, wss[q].Z, wv, m)
+            worst["residual"] = max(worst["residual"], res)
+            worst["b_orthonormality"] = max(worst["b_orthonormality"], bo)
+            assert res <= n * EPS and bo <= 1e-10, (g0 + q, res, bo)
+        if g0 == 0:
+            w0 = wss[0].w[:n].clone()
+            A0, B0 = prist[0]
+            info, ws1 = api.hegvdx(A0.clone(), B0.clone(), 1, m)
+            assert info == 0 and torch.equal(ws1.w[:n], w0) and torch.equal(ws1.Z[:m], wss[0].Z[:m])
+            # all N generalized eigenvalues are returned (zheevd_gpu.F90:111): their sum is trace(B^-1 A)
+            tr = float(torch.linalg.solve(B0.T, A0.T).diagonal().real.sum())
+            assert abs(float(w0.sum()) - tr) <= 1e-9 * abs(tr)
+        del prist, work
+    _report("C5_full_batch_64_problems", dict(worst, N_eps=n * EPS, problems=NP, per_call=F))
 
 
 def test_c5_batch_through_the_sharding_module(env):
