@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
 //    before the MFMAs of slab k, ONE barrier per stage.
 // ------------------------------------------------------------------------------------------------
 template <class T, int BM, int BN, int TA, int TB, int BK, bool MASKED>
-__global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
+__global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     constexpr bool CX = Tr<T>::cx;
     constexpr int NPL = CX ? 2 : 1;
     constexpr int LDA = TA == 0 ? BM + 16 : BK + 2;
@@ -463,13 +463,27 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
         if (nst > 1) gload(kbeg + BK);
         __syncthreads();
     }
-    for (int s_ = 0; s_ < nst; ++s_) {
-        const double* As = sm + (s_ & 1) * STG;
-        const double* Bs = As + NPL * ASZ;
-        if (s_ + 1 < nst) {
-            lstore(sm + ((s_ + 1) & 1) * STG);                 // slab s+1 (registers) -> other buffer
-            if (s_ + 2 < nst) gload(kbeg + (s_ + 2) * BK);     // slab s+2 in flight during the MFMAs
-        }
+    // C of the tile (beta != 0): requested BEFORE the MFMAs of the last slab -- the operand staging registers are dead by then --
+    // so that the read-modify-write epilogue does not start with an exposed memory round trip (at K = 64, four slabs per tile,
+    // that round trip was ~20 % of a tile: rank-64 update of potrf 33.8 TFLOP/s against 43 for the same product with beta = 0)
+    const bool use_c = g.kchunk == 0 && !(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0);
+    T cv[TM][TN][4];
+    auto load_c = [&]() {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int gi = i0 + wm0 + a * 16 + (lane & 15);
+                    int gj = j0 + wn0 + b * 16 + (lane >> 4) + 4 * r;
+                    bool ok = gi < g.M && gj < g.N;
+                    const T* cp = ok ? g.C + (size_t)gi + (size_t)gj * g.ldc : g.C;
+                    cv[a][b][r] = *cp;
+                }
+    };
+    // the MFMAs of one K-slab (As / Bs: the LDS stage holding it)
+    auto mma_slab = [&](const double* As, const double* Bs) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double ar[TM], ai[TM], br[TN][4], bi[TN][4];
@@ -515,28 +529,25 @@ __global__ void __launch_bounds__(256) gemm_fast_kernel(GemmArgs<T> g) {
                 }
             }
         }
+    };
+    // all slabs but the last: stage slab s+1, request slab s+2, multiply slab s
+    for (int s_ = 0; s_ + 1 < nst; ++s_) {
+        const double* As = sm + (s_ & 1) * STG;
+        lstore(sm + ((s_ + 1) & 1) * STG);                 // slab s+1 (registers) -> other buffer
+        if (s_ + 2 < nst) gload(kbeg + (s_ + 2) * BK);     // slab s+2 in flight during the MFMAs
+        mma_slab(As, As + NPL * ASZ);
         __syncthreads();
     }
-
-    // epilogue, branch-free on the load side: all C reads of the tile are issued together (clamped
-    // addresses), then combined and stored under a predicate.  (`if (valid) { load; store; }` per
-    // element serialises 16 dependent round trips -- the same hipcc pattern as in the operand loads.)
-    const bool use_c = g.kchunk == 0 && !(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0);
-    T cv[TM][TN][4];
-    if (use_c) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int gi = i0 + wm0 + a * 16 + fi;
-                    int gj = j0 + wn0 + b * 16 + fk + 4 * r;
-                    bool ok = gi < g.M && gj < g.N;
-                    const T* cp = ok ? g.C + (size_t)gi + (size_t)gj * g.ldc : g.C;
-                    cv[a][b][r] = *cp;
-                }
+    // the last slab, with C in flight (peeled: cv is live only here, so the kernel stays at two workgroups per CU)
+    if (use_c) load_c();
+    if (nst > 0) {
+        const double* As = sm + ((nst - 1) & 1) * STG;
+        mma_slab(As, As + NPL * ASZ);
     }
+
+    // epilogue, branch-free on the load side: all C reads of the tile were issued together (clamped addresses, load_c above),
+    // here they are combined and stored under a predicate.  (`if (valid) { load; store; }` per element serialises 16
+    // dependent round trips -- the same hipcc pattern as in the operand loads.)
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll

@@ -17,9 +17,11 @@ rm -rf /tmp/tr; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr -o c3
 python $R/tools/trace_phases.py $(find /tmp/tr -name "*.db" | head -1) --list potrf,bt,trsm $O/r03_phase_trace_c3.txt > /dev/null
 rm -rf /tmp/tr2; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr2 -o c2 -- python $R/tools/solve_trace.py 2048 512 1 real > $O/trace_c2.log 2>&1
 python $R/tools/trace_phases.py $(find /tmp/tr2 -name "*.db" | head -1) $O/r03_phase_trace_c2.txt > /dev/null
-# (4) counters
-cd $R; bash tools/pmc_collect.sh gpurun_out/r03_pmc $O/r03_pmc_summary.txt $O/r03_hemv_traffic.json
-# (5) un-traced bench lines
+# (4) counters (bounded: counter collection serialises every dispatch)
+cd $R; timeout 600 bash tools/pmc_collect.sh gpurun_out/r03_pmc $O/r03_pmc_summary.txt $O/r03_hemv_traffic.json
+# (5) un-traced bench lines: the default (C3), C2, C5 as the timed workload, C4
 python bench.py > $O/r03_bench_c3.json 2> $O/r03_bench_c3.err
 python bench.py --real --n 2048 --no-c5 > $O/r03_bench_c2_dsygvdx_n2048.json 2> $O/r03_bench_c2.err
+python bench.py --workload c5 --steps 3 --no-cpu-baseline --no-host-tridiag > $O/r03_bench_c5_1gpu.json 2> $O/r03_bench_c5.err
+python bench.py --n 8192 --m 8192 --batch 1 --steps 2 --warmup 1 --no-c5 --no-cpu-baseline --no-host-tridiag --same-problems > $O/r03_bench_c4_n8192_full.json 2> $O/r03_bench_c4.err
 ls -la $O
