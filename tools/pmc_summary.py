@@ -50,22 +50,35 @@ KNOWN = {
 }
 
 rows = []
+small = defaultdict(lambda: {"c": defaultdict(list), "dur": [], "n": 0})     # per name: the (name, grid) entries below the cut
+CUT = 150.0
 for k in acc:
     if "eig::" not in k:
         continue
-    c = {cn: sum(v) / len(v) for cn, v in acc[k].items()}
     nm, g = short(k)
     ncall = max(len(v) for v in acc[k].values())
     us = sum(dur[k]) / len(dur[k]) / 1e3
+    if us * ncall < CUT and "panel_mv" not in nm:
+        sm_ = small[nm]
+        for cn, v in acc[k].items():
+            sm_["c"][cn].extend(v)
+        sm_["dur"].extend(dur[k])
+        sm_["n"] += ncall
+        continue
+    c = {cn: sum(v) / len(v) for cn, v in acc[k].items()}
     rows.append((us * ncall, nm, g, ncall, us, c))
+for nm, sm_ in small.items():       # launches of one kernel over many grids (the Cholesky block rows, shrinking updates): one row
+    us = sum(sm_["dur"]) / len(sm_["dur"]) / 1e3
+    if us * sm_["n"] < CUT:
+        continue
+    c = {cn: sum(v) / len(v) for cn, v in sm_["c"].items()}
+    rows.append((us * sm_["n"], nm, "(various)", sm_["n"], us, c))
 rows.sort(key=lambda r: -r[0])
 hdr = "%-46s %9s %6s %10s %7s %7s   %-17s %10s %10s" % ("kernel", "grid", "calls", "avg us", "MFMA %", "TF/s", "iss/stall/wait", "HBM MB", "algo MB")
 print("# rocprofv3 --kernel-trace --pmc passes over tools/pmc_targets.py: per-dispatch averages (see the header of tools/pmc_summary.py)")
 print(hdr)
 hemv = None
 for tot, nm, g, ncall, us, c in rows:
-    if tot < 20.0 and "panel_mv" not in nm:
-        continue          # (launches that add up to less than 20 us over the whole run are left out of the table)
     mf = tf = None
     if c.get("SQ_BUSY_CYCLES", 0) > 0 and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
         mf = (c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (c["SQ_BUSY_CYCLES"] / 32.0) * 100.0

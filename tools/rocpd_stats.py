@@ -13,23 +13,37 @@ lines = ["# rocprofv3 --kernel-trace --stats summary (from %s)" % sys.argv[1], "
          "%-100s %8s %12s %10s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "%")]
 for r in rows:
     lines.append("%-100s %8d %12.3f %10.2f %10.2f %10.2f %6.1f" % (r[0][:100], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
-# the roofline leg of bench.py: the longest run of consecutive panel_mv_kernel launches with no panel_row_kernel in
-# between (hetrd_mv_sweep replays the mat-vec launches of one tridiagonalization back to back on an idle GPU)
-seq = list(cur.execute("select name, start, end from kernels order by start"))
-best = (0, 0, 0); run_start = None; run_len = 0
-for idx, (nm, st, en) in enumerate(seq + [("", 0, 0)]):
+# the roofline leg of bench.py: hetrd_mv_sweep replays the mat-vec launches of one tridiagonalization back to back on an idle
+# GPU (no panel_row_kernel in between), several times (warm-up + repetitions, and once more for order 8192).  A sweep walks the
+# trailing order DOWN, so a new sweep starts where the grid of a panel_mv_kernel launch jumps back up; sweeps are reported
+# one by one (launch count, average duration) -- the first order's repetitions are the ones `roofline.avg_launch_us` refers to.
+seq = list(cur.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
+runs, cur_run = [], []
+for nm, st, en, gx, wx in seq + [("", 0, 0, 0, 1)]:
     if "panel_mv_kernel" in nm:
-        if run_len == 0: run_start = idx
-        run_len += 1
-    elif "panel_row_kernel" in nm or nm == "":
-        if run_len > best[0]: best = (run_len, run_start, idx)
-        run_len = 0
-if best[0] > 100:
-    sw = [r for r in seq[best[1]:best[2]] if "panel_mv_kernel" in r[0]]
-    avg = sum(e - s for _, s, e in sw) / len(sw) / 1e3
+        cur_run.append((st, en, gx // max(wx, 1)))
+    else:
+        if "panel_row_kernel" in nm or nm == "":
+            if len(cur_run) > 100:
+                runs.append(cur_run)
+            cur_run = []
+if runs:
+    best = max(runs, key=len)
+    sweeps, cur_s = [], []
+    prev = None
+    for st, en, g in best:
+        if prev is not None and g > 1.5 * prev and len(cur_s) > 50:
+            sweeps.append(cur_s)
+            cur_s = []
+        cur_s.append((st, en))
+        prev = g
+    if cur_s:
+        sweeps.append(cur_s)
     lines.append("")
-    lines.append("roofline sweep (bench.py `roofline` leg): %d consecutive panel_mv_kernel launches, avg %.2f us, total %.3f ms"
-                 % (len(sw), avg, sum(e - s for _, s, e in sw) / 1e6))
+    for k, sw in enumerate(sweeps):
+        avg = sum(e - s for s, e in sw) / len(sw) / 1e3
+        lines.append("roofline sweep %d (bench.py `roofline` leg): %d consecutive panel_mv_kernel launches, avg %.2f us, total %.3f ms"
+                     % (k, len(sw), avg, sum(e - s for s, e in sw) / 1e6))
 txt = "\n".join(lines)
 print(txt)
 if len(sys.argv) > 2:
