@@ -35,11 +35,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The in-flight default (3 problems per GPU) was tuned with the ROCm default of 4 hardware queues per process: with two
-# streams per library context two of the three solves then share one hardware queue.  Measured at C3: 8 or 16 queues
-# (three-way hardware concurrency of dependent-launch chains) 8.3-8.7 problems/s, 1-2 queues 10.0, 4 queues 15.8
-# (profiles/r02_experiments.txt).  Pin the value the numbers were measured with.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")
+# Hardware queues.  Every launch chain of a batch wants a hardware queue of its own next to the null stream's; ROCm gives a
+# process 4 by default, which fits 3 problems in flight (16.1 problems/s at C3, 68 at C5).  Allowing more lets the library run 4
+# chains -- its automatic choice when GPU_MAX_HW_QUEUES >= 5: 16.4 at C3, 83 at C5 (the latency-bound small orders gain most;
+# flat for 5 / 6 / 8 / 16).  This is the documented ROCm knob a batch integrator sets.  The result no
+# longer depends on stream creation order (round 2: a 2x swing at 8 queues) -- the library leases one stream per call.  An
+# explicit value in the environment wins.  Must happen before the HIP runtime starts (torch import).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TF = 78.6    # MI355X datasheet fp64 matrix
@@ -111,14 +113,15 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the `c5` object of the default line")
     ap.add_argument("--c5-order", type=int, default=2048, help="order of the `c5` object's problems (tests shrink it)")
     ap.add_argument("--no-host-tridiag", action="store_true")
-    ap.add_argument("--batch", type=int, default=3, help="(c3) independent problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=4, help="(c3) independent problems per GPU per step (4 = one per launch chain the "
+                    "library runs with 8 hardware queues allowed)")
     ap.add_argument("--inflight", type=int, default=1, help="host threads per GPU issuing solver calls (persistent, one library "
                     "context each); default 1: the concurrency lives inside the library (--workers)")
     ap.add_argument("--fuse", type=int, default=0, help="problems per solver call (eigsolve_?hegvdx_batch); 0 (default) = the whole "
                     "batch of a step in one call (c5: 8 per call); 1 = the reference's one-problem-per-call driver")
-    ap.add_argument("--workers", type=int, default=3, help="library option batch_workers: problems in flight inside one batch call "
-                    "(0 = lockstep tridiagonalizations on the caller's context); measured at C3: 2 -> 14.7, 3 -> 16.0, 4 -> 14.1 "
-                    "problems/s with the default 4 hardware queues (4 -> 16.3 with GPU_MAX_HW_QUEUES=8)")
+    ap.add_argument("--workers", type=int, default=-1, help="library option batch_workers: problems in flight inside one batch call "
+                    "(-1 = automatic: 4 when GPU_MAX_HW_QUEUES >= 5, else 3; 0 = lockstep tridiagonalizations on the caller's "
+                    "context); measured at C3: 2 -> 14.7, 3 -> 16.0, 4 -> 16.3 (8 queues) / 14.1 (4 queues), 5 -> 12.4")
     ap.add_argument("--isolated-reps", type=int, default=3, help="isolated single solves timed before the batch (median/min reported)")
     ap.add_argument("--tridiag", choices=["device", "host"], default="device",
                     help="tridiagonal eigensolver: device divide&conquer (default) or host LAPACK dstedc (reference behaviour)")
@@ -177,6 +180,7 @@ def main():
         api.init_eigsolve_gpu()                # the worker's library context
         api.set_option("tridiag", tri)
         api.set_option("batch_workers", args.workers)
+    eff_workers = args.workers if args.workers >= 0 else (4 if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 5 else 3)
 
     pool = InflightPool(nthr, init=worker_init)
 
@@ -307,7 +311,7 @@ def main():
         name = "zhegvdx" if cplx else "dsygvdx"
         if fuse > 1:
             how = ("%d host thread(s) per GPU, %d problems per eigsolve_%s_batch call, the library keeps %d of them in flight on its own "
-                   "worker threads" % (nthr, fuse, name, args.workers)) if args.workers > 0 else \
+                   "worker threads (GPU_MAX_HW_QUEUES=%s)" % (nthr, fuse, name, eff_workers, os.environ.get("GPU_MAX_HW_QUEUES", "default"))) if eff_workers > 0 else \
                   ("%d host thread(s) per GPU, %d problems per eigsolve_%s_batch call, tridiagonalizations in lockstep" % (nthr, fuse, name))
         else:
             how = "%d one-problem calls in flight per GPU (one persistent host thread + library context each)" % nthr
@@ -335,8 +339,9 @@ def main():
             "data": "synthetic (reference recipe A=T*T^H, B=T'*T'^H, uniform[0,1) entries, seeded; every problem distinct)",
             "config": {"workload": workload, "lda": n, "il": 1, "iu": m, "problems_per_step_total": n_total,
                        "problems_per_gpu_per_step": len(mine), "host_threads_per_gpu": nthr, "problems_per_solver_call": fuse,
-                       "library_batch_workers": args.workers if fuse > 1 else None,
-                       "inflight_per_gpu": (args.workers if args.workers > 0 else fuse) * nthr if fuse > 1 else nthr,
+                       "library_batch_workers": eff_workers if fuse > 1 else None,
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
+                       "inflight_per_gpu": (eff_workers if eff_workers > 0 else fuse) * nthr if fuse > 1 else nthr,
                        "parallelism": "batch-over-gpus x%d" % world},
             "ms_per_solve": sorted(iso)[len(iso) // 2],
             "ms_per_solve_min": min(iso),

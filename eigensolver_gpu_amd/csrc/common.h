@@ -165,8 +165,9 @@ struct Ctx {
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
     int trd_fuse = -1;       // >= 0: order below which panels use panel_col_kernel (0 = never); -1 = default per type
-    int batch_workers = 3;   // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
-                             // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip)
+    int batch_workers = -1;  // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
+                             // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip);
+                             // -1 = automatic, see auto_batch_workers()
     int trace_marks = 0;     // EIGSOLVE_TRACE_MARKS=1: marker kernels at the phase boundaries (profiling aid, see evd.hip)
 
     template <class T> T* scratch(const char* name, size_t count) {
@@ -194,7 +195,8 @@ struct StreamLease {
     StreamLease(const StreamLease&) = delete;
     StreamLease& operator=(const StreamLease&) = delete;
 };
-void copy_options(Ctx& dst, const Ctx& src);   // all tunables of src (eigsolve_set_option / environment) into dst
+void copy_options(Ctx& dst, const Ctx& src);
+int auto_batch_workers();   // 4 when the process has asked for >= 5 hardware queues (GPU_MAX_HW_QUEUES), else 3   // all tunables of src (eigsolve_set_option / environment) into dst
 
 // The library's own worker threads (context.cpp): runs fn(0) ... fn(ntasks-1) on `nworkers` of them, device `dev` current,
 // each worker taking the next task as it finishes one; returns when all are done.  A worker keeps its per-thread context

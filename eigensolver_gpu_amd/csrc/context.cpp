@@ -178,6 +178,16 @@ void Ctx::release() {
     if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);
 }
 
+// How many launch chains of a batch run side by side: every chain wants a hardware queue of its own next to the null stream's, and
+// the part serves FOUR queues concurrently -- measured (profiles/r03_experiments.txt, section 10): 3 / 4 chains with 8 queues allowed
+// 16.0 / 16.3 problems/s at C3 and 67.7 / 82.8 at C5, but 5, 6, 8 chains 55 / 52 / 46 (C5) however many queues are allowed, and 4
+// chains on the default 4 queues (one shared with another chain) 55.9.  So: 4 when the process allows >= 5 queues
+// (GPU_MAX_HW_QUEUES, read by the HIP runtime at start-up; ROCm's default is 4), otherwise 3.
+int auto_batch_workers() {
+    const char* e = getenv("GPU_MAX_HW_QUEUES");
+    return (e && atoi(e) >= 5) ? 4 : 3;
+}
+
 void copy_options(Ctx& c, const Ctx& d) {
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
@@ -297,7 +307,7 @@ static void init_options(Ctx& c) {
     if (const char* e = getenv("EIGSOLVE_TRD_FUSE")) c.trd_fuse = atoi(e);
     if (c.trd_fuse > 8192) c.trd_fuse = 8192;
     if (const char* e = getenv("EIGSOLVE_BATCH_WORKERS")) c.batch_workers = atoi(e);
-    if (c.batch_workers < 0 || c.batch_workers > 16) c.batch_workers = d.batch_workers;
+    if (c.batch_workers < -1 || c.batch_workers > 16) c.batch_workers = d.batch_workers;
     if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRACE_MARKS")) c.trace_marks = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
@@ -492,7 +502,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? eig::kGstModeDefault : value;
         else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
         else if (s == "trd_fuse") { c.trd_fuse = value < 0 ? -1 : (value > 8192 ? 8192 : value); c.drop_graphs(); }
-        else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? 3 : value;
+        else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

@@ -575,7 +575,7 @@ static int hegvdx_batch_workers(Ctx& c0, int nprob, int N, T* const* A, int lda,
                                 T* const* Z_h, int ldz_h, int skip_host_copy, int* infos, const char* name) {
     clear_phases(c0);
     const double t_all = now_ms();
-    batch_run(c0.dev, c0.batch_workers, nprob, [&](int q) {
+    batch_run(c0.dev, c0.batch_workers < 0 ? auto_batch_workers() : c0.batch_workers, nprob, [&](int q) {
         guarded(&infos[q], [&]() -> int {
             Ctx& c = ctx();
             copy_options(c, c0);
@@ -713,7 +713,7 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
             A[q] = (cplx*)A_d[q]; B[q] = (cplx*)B_d[q]; Z[q] = (cplx*)Z_d[q]; Zh[q] = Z_h ? (cplx*)Z_h[q] : nullptr;
             tau[q] = (cplx*)work_d[q]; W[q] = (cplx*)work_d[q] + n; e[q] = rwork_d[q];       // carve-up of zheevd_gpu.F90:68-75
         }
-        if (c.batch_workers > 0)
+        if (c.batch_workers != 0)
             return hegvdx_batch_workers<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
                                               W.data(), w_h, Z_h ? Zh.data() : nullptr, ldz_h, skip_host_copy, info, "zhegvdx_gpu");
         return hegvdx_batch_core<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
@@ -741,7 +741,7 @@ int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double
         if (!c.tridiag_device) { printf(" dsygvdx_gpu batch error: the batch driver needs the device tridiagonal solver (tridiag = 1)\n"); return -1; }
         std::vector<double*> e(nprob), tau(nprob), W(nprob);
         for (int q = 0; q < nprob; ++q) { e[q] = work_d[q]; tau[q] = work_d[q] + n; W[q] = work_d[q] + 2 * n; }   // dsyevd_gpu.F90:68-74
-        if (c.batch_workers > 0)
+        if (c.batch_workers != 0)
             return hegvdx_batch_workers<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h,
                                                 Z_h, ldz_h, skip_host_copy, info, "dsygvdx_gpu");
         return hegvdx_batch_core<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h, Z_h,

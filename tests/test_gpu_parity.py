@@ -1335,7 +1335,7 @@ def test_bench_eight_ranks_on_one_gpu(env):
                          timeout=1200, env=envv)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 8 and d["config"]["problems_per_step_total"] == 24 and d["eigenvalues_gathered"] == [24, 64]
+    assert d["n_gpus"] == 8 and d["config"]["problems_per_step_total"] == 32 and d["eigenvalues_gathered"] == [32, 64]
     assert d["c5"]["gathered_eigenvalues_shape"] == [64, 64] and d["c5"]["problems_per_gpu"] == 8
     assert d["c5"]["rerun_bit_identical"] is True and len(d["c5"]["pass_ms_min_median_max"]) == 3
 
