@@ -41,7 +41,7 @@ int eigsolve_set_host_threads(int nthreads);
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
  * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance","batch_workers"};
  * value<=0 restores the default, except where 0 is itself a setting: "tridiag", "gst", "overlap" (value<0 restores the
- * default), "potrf" (0 = recursive form, anything else = block rows), "batch_workers" (0 = lockstep form, value<0 or >16 = default 3).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
+ * default), "potrf" (0 = recursive form, anything else = block rows), "batch_workers" (0 = lockstep form, value<0 or >16 = automatic).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
  * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
@@ -51,7 +51,8 @@ int eigsolve_set_host_threads(int nthreads);
  * gets slower (bit 1 alone: back-transform -1.1 ms, whole solve +13 ms), so 0 (default) = single stream.
  * "bt_nb": reflectors per block of the back-transformation: 64 (the reference's larfb width), 128, 256 (default) or 512 --
  * 64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
- * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default 3; 0 = lockstep form).
+ * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default automatic: 4 when the process allows
+ * >= 5 hardware queues through GPU_MAX_HW_QUEUES, else 3; 0 = lockstep form).
  * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
  * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
  * larger than "gst_thr" (default 1024), two solves below.
@@ -102,9 +103,9 @@ int eigsolve_dsygvdx(int N, double *A_d, int lda, double *B_d, int ldb, double *
                      int liwork_h, double *Z_h, int ldz_h, double *w_h, int *info, int skip_host_copy);
 
 /* Batch of nprob problems of ONE order (QE k-point style, BASELINE.json configs[4]) solved by one call from one host thread.
- * The library keeps "batch_workers" (default 3) of the problems in flight on its own worker threads -- the caller's thread
- * is one of them --, each problem an ordinary single-problem solve on a context and stream of its own, so that the
- * latency-bound phases of one solve fill under the kernels of the others (C3: 16.0 problems/s against 10.3 for one call
+ * The library keeps "batch_workers" (automatic: 3, or 4 with GPU_MAX_HW_QUEUES >= 5) of the problems in flight on its own
+ * worker threads -- the caller's thread is one of them --, each problem an ordinary single-problem solve on a context and stream of its own, so that the
+ * latency-bound phases of one solve fill under the kernels of the others (C3: 16.4 problems/s against 10.3 for one call
  * per problem).  "batch_workers" = 0: everything on the caller's context, the tridiagonalizations in LOCKSTEP (every
  * per-column launch carries all problems), the other phases problem after problem.  Arguments as eigsolve_zhegvdx /
  * eigsolve_dsygvdx with one pointer per problem (host arrays of nprob device / host pointers, no null entries; Z_h may be
