@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
     __shared__ double sm[2 * STG];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (wave index made wave-uniform for the compiler: the wave's tile origin and LDS offsets then live in SGPRs, 2-5 VGPRs less)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // strided batch: entry zb works on operands / output shifted by constant strides, with its own K, mask offsets and
     // (clipped) M, N -- all wave-uniform
     const int pld = g.M;          // leading dimension of the split-K partial blocks
@@ -619,10 +620,12 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits) {
     const bool cat_ok = !cat || (g.A.k1 == g.B.k1 && g.A.k1 % BK == 0);
     if (g_use_fast && cat_ok) {
         const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
+        // experiment knob (profiles/r03_experiments.txt 11): dynamic LDS added to every product workgroup, i.e. ONE workgroup per CU
+        static const unsigned pad = getenv("EIGSOLVE_GEMM_LDSPAD") ? (unsigned)atoi(getenv("EIGSOLVE_GEMM_LDSPAD")) : 0u;
 #define EIG_LAUNCH_FAST(TA_, TB_)                                                                                        \
     do {                                                                                                                 \
-        if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, 0, st, g);        \
-        else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, false>), grid, block, 0, st, g);              \
+        if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, pad, st, g);      \
+        else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, false>), grid, block, pad, st, g);            \
     } while (0)
         if (ta == 0 && tb == 0) EIG_LAUNCH_FAST(0, 0);
         else if (ta == 0 && tb == 1) EIG_LAUNCH_FAST(0, 1);

@@ -314,7 +314,7 @@ static void init_options(Ctx& c) {
     if (const char* e = getenv("EIGSOLVE_BT_NB")) c.bt_nb = atoi(e);
     if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c.hemv_blocks = atoi(e);
     if (const char* e = getenv("EIGSOLVE_P_WT")) c.p_wt = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c.hemv_balance = atoi(e) != 0;
+    if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c.hemv_balance = atoi(e);
     if (const char* e = getenv("EIGSOLVE_GRAPH")) c.use_graph = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_OVERLAP")) c.overlap = atoi(e) & 3;
     if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c.trsm_base = norm_trsm_base(atoi(e));
@@ -492,7 +492,7 @@ int eigsolve_set_option(const char* name, int value) {
         if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
         else if (s == "bt_nb") c.bt_nb = eig::norm_bt_nb(value);
         else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
-        else if (s == "hemv_balance") { c.hemv_balance = value != 0; c.drop_graphs(); }   // baked into captured launch sequences
+        else if (s == "hemv_balance") { c.hemv_balance = value < 0 ? 0 : value; c.drop_graphs(); }   // baked into captured launch sequences
         else if (s == "p_wt") { c.p_wt = value != 0; c.drop_graphs(); }
         else if (s == "real_il_reference") c.real_il_reference = value > 0;
         else if (s == "graph") c.use_graph = value > 0;

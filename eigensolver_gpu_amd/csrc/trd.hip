@@ -1045,9 +1045,9 @@ static int hemv_grid(const Ctx& c, int n) {
     // round plus 16 tiles that run alone.  Spreading the tiles evenly over the minimum number of rounds (G = 264 x 2 tiles)
     // was measured SLOWER (n=2048: 10.1 vs 9.0 us per launch; C3 tridiagonalization 71.2 vs 69.2 ms): two resident
     // workgroups per CU hide more latency than the balanced tail saves.  Kept as option "hemv_balance" (off).
-    if (c.hemv_balance) {
+    if (c.hemv_balance > 0) {   // k: balance when the tiles make at least k rounds
         long rounds = (ntiles + cap - 1) / cap;
-        return (int)((ntiles + rounds - 1) / rounds);
+        if (rounds >= c.hemv_balance) return (int)((ntiles + rounds - 1) / rounds);
     }
     return (int)cap;
 }

@@ -16,7 +16,10 @@ s = 16 if cplx else 8
 A = torch.randn((N, N), dtype=dt, device="cuda")
 x = torch.randn(N, dtype=dt, device="cuda")
 print("# n  us/launch  TB/s(algorithmic s*n(n+1)/2)  tiles")
-for n in (64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 3072, 3584, 4096):
+ns = (64, 128, 256, 384, 512, 768, 1024, 1280, 1536, 1792, 2048, 2304, 2560, 3072, 3584, 4096)
+if os.environ.get("HEMV_CURVE_FINE"):
+    ns = tuple(range(1984, N + 1, 128))
+for n in ns:
     if n > N:
         break
     ms = api.hemv_bench(A, x, reps=200, n=n)
