@@ -104,10 +104,14 @@ template <class T> void build_inv_blocks(Ctx& c, hipStream_t st, int N, const T*
 // A <- U^-H A U^-1 (upper triangle only is read/written).
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
-// potrf(B) and hegst(A, U) with the two launch chains overlapped on c.s1 / c.s2 at the top level of the
-// recursion: while s1 factors the trailing half of B, s2 already reduces the leading half of A (which only
-// needs U11, U12).  Joins on c.s1.  On a non-positive-definite B the upper triangle of A is unspecified.
-template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb);
+// potrf(B) || hegst(A, U) pipeline (option "overlap" bit 0; see blas3.hip): *_begin enqueues the whole factorization on
+// c.s1 and the steps of hegst's top level that only need the leading half of the factor on the second stream; the caller
+// synchronises c.s1 for potrf's info, then calls *_finish (join + the two steps that need U22).  Bit-identical to
+// potrf_upper + hegst_upper.  On a non-positive-definite B the upper triangle of A is unspecified (the caller must
+// synchronise the second stream before returning).
+template <class T> bool pipeline_applicable(const Ctx& c, int N);
+template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda, T* B, int ldb);
+template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, const T* U, int ldu);
 
 inline constexpr int kDiagBlk = 64;  // order of the inverted diagonal blocks
 

@@ -812,13 +812,13 @@ constexpr int DGT = NTD * NTD;   // = 1024: four waves per SIMD, to overlap the 
 //   inverse written to invU (DB x DB, ld DB, identity-padded, zero below the diagonal).
 template <class T>
 __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, int ldu, T* invU, int do_chol, int k0_single,
-                                                         int* info) {
+                                                         int* info, int blk0) {
     __shared__ T rowb[2][DB];
     __shared__ T colb[2][DB];
     __shared__ T dinvs[DB];   // reciprocals of the diagonal of U
     const int tid = threadIdx.x;
     const int tr = tid / NTD, tc = tid % NTD;
-    const int blk = (k0_single >= 0) ? k0_single / DB : blockIdx.x;
+    const int blk = (k0_single >= 0) ? k0_single / DB : blk0 + (int)blockIdx.x;
     const int k0 = blk * DB;
     const int nb = min(DB, n_total - k0);
     T* Ublk = Umat + (size_t)k0 + (size_t)k0 * ldu;
@@ -1444,7 +1444,7 @@ template <class T>
 static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int ldb, T* invU, bool use256 = false, bool block_root = false) {
     if (n <= 0) return;
     if (n <= DB) {
-        hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(DGT), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info);
+        hipLaunchKernelGGL((diag_block_kernel<T>), dim3(1), dim3(DGT), 0, st, Ntot, B, ldb, invU, 1, k0, c.d_info, 0);
         EIG_HIP(hipGetLastError());
         if (use256 && block_root) build_inv256_groups<T>(c, st, Ntot, (const T*)B, ldb, k0 / BB, 1);
         return;
@@ -1474,6 +1474,34 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 // broadcast, barrier): a 4x4-cyclic 256-thread layout, a scaled look-ahead broadcast and a blocked-by-16 elimination (rank-16
 // updates, 16x fewer barriers per multiply-add) all measured 40-44 us per launch like this one (profiles/r02_experiments.txt;
 // kernels in the git history of round 2).
+// block rows kb0 .. kb1-1 of the right-looking factorization (`expect`: the cumulative announce count of chol_row_kernel)
+template <class T> static void potrf_block_rows(Ctx& c, hipStream_t st, int N, T* B, int ldb, int kb0, int kb1, unsigned& expect) {
+    unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 2;   // its own word (d_info[1] is stedc's), zeroed by the caller
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int k0 = kb * DB;
+        const int nb = min(DB, N - k0), rem = N - k0 - nb;
+        const int chunks = (rem + DB - 1) / DB;
+        expect += (unsigned)chunks;
+        hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
+        if (rem > 0) {
+            const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
+            Epi e; e.uplo = 1; e.herm_diag = 1;
+            gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
+                    B + (size_t)(k0 + nb) + (size_t)(k0 + nb) * ldb, ldb, e);
+        }
+    }
+    EIG_HIP(hipGetLastError());
+}
+
+// inverses of the 64x64 diagonal blocks blk0 .. blk0+nb-1 of a finished factor
+template <class T> static void build_invU_range(Ctx& c, hipStream_t st, int N, const T* U, int ldu, int blk0, int nb) {
+    const int nblk = (N + DB - 1) / DB;
+    if (nb <= 0) return;
+    T* invU = c.scratch<T>("invU", (size_t)nblk * DB * DB);
+    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nb), dim3(DGT), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1, c.d_info, blk0);
+    EIG_HIP(hipGetLastError());
+}
+
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb) {
     int nblk = (N + DB - 1) / DB;
     T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
@@ -1481,33 +1509,15 @@ template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb
     if (c.potrf_mode == 0) {
         potrf_rec(c, st, N, N, 0, B, ldb, invU);
     } else {
-        unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 2;   // its own word (d_info[1] is stedc's), zeroed above
         unsigned expect = 0;
-        for (int k0 = 0; k0 < N; k0 += DB) {
-            const int nb = min(DB, N - k0), rem = N - k0 - nb;
-            const int chunks = (rem + DB - 1) / DB;
-            expect += (unsigned)chunks;
-            hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
-            if (rem > 0) {
-                const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
-                Epi e; e.uplo = 1; e.herm_diag = 1;
-                gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
-                        B + (size_t)(k0 + nb) + (size_t)(k0 + nb) * ldb, ldb, e);
-            }
-        }
-        EIG_HIP(hipGetLastError());
+        potrf_block_rows<T>(c, st, N, B, ldb, 0, nblk, expect);
         build_invU<T>(c, st, N, (const T*)B, ldb);
     }
     build_inv_blocks<T>(c, st, N, (const T*)B, ldb);
 }
 
 template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu) {
-    int nblk = (N + DB - 1) / DB;
-    if (nblk <= 0) return;
-    T* invU = c.scratch<T>("invU", (size_t)nblk * DB * DB);
-    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nblk), dim3(DGT), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1,
-                       c.d_info);
-    EIG_HIP(hipGetLastError());
+    build_invU_range<T>(c, st, N, U, ldu, 0, (N + DB - 1) / DB);
 }
 
 template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu) {
@@ -1691,62 +1701,72 @@ template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A
     EIG_HIP(hipGetLastError());
 }
 
-template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
-    hipStream_t s1 = c.s1, s2 = c.second_stream();
-    int nblk = (N + DB - 1) / DB;
-    T* invU = c.scratch<T>("invU", (size_t)(nblk > 0 ? nblk : 1) * DB * DB);
-    EIG_HIP(hipMemsetAsync(c.d_info, 0, sizeof(int), s1));
-    if (N <= 2 * DB) {
-        potrf_rec(c, s1, N, N, 0, B, ldb, invU);
-        hegst_rec(c, s1, N, 0, A, lda, (const T*)B, ldb);
-        return;
-    }
-    const int n1 = split_n1(N), n2 = N - n1;
-    T* B12 = B + (size_t)n1 * ldb;
-    T* B22 = B + (size_t)n1 + (size_t)n1 * ldb;
+// ---- potrf || hegst pipeline (option "overlap" bit 0) ----------------------------------------------------------------
+// The second half of the block-row Cholesky is a chain of small launches (64 workgroups per block-row kernel, short rank-64
+// updates: 2 ms at C3 with most of the chip idle), and most of hegst's top level only needs the FIRST half of the factor:
+//     hegst(A11, U11),  A12 <- U11^-H A12,  A12 -= 1/2 Herm(A11) U12,  A22 -= A12^H U12 + U12^H A12,  A12 -= 1/2 Herm(A11) U12
+// (zhegst_gpu.F90:57-101 with the block = the leading half).  So: block rows of the leading half on the call's stream, then
+// the rest of the factorization on that stream WHILE the second (low-priority) stream runs those hegst steps; after the join
+// the two steps that need U22 (A12 <- A12 U22^-1, hegst(A22, U22)).  Same kernels, same operands, same order of operations
+// on every block as the sequential path: results are bit-identical.  Only used for a solve that has the device to itself
+// (the caller checks the stream pool): with several solves in flight the chip is full anyway and every extra stream costs
+// a hardware queue (profiles/r03_experiments.txt 5, 10).
+template <class T> bool pipeline_applicable(const Ctx& c, int N) {
+    return c.gst_mode == 2 && c.potrf_mode != 0 && norm_base(c.trsm_base) == BB && N > c.gst_thr && N >= 2 * BB;
+}
+
+template <class T> static void hegst_top_part1(Ctx& c, hipStream_t st, int n, T* A, int lda, const T* U, int ldu, int thr, int n1) {
+    const int n2 = n - n1;
+    hegst_hybrid(c, st, n1, 0, A, lda, U, ldu, thr);
+    T* A11 = A;
     T* A12 = A + (size_t)n1 * lda;
     T* A22 = A + (size_t)n1 + (size_t)n1 * lda;
+    const T* U12 = U + (size_t)n1 * ldu;
     const T mhalf = Tr<T>::make(-0.5, 0.0);
-    // s2 must not start before everything already queued on s1 (caller's data, the memset) is done
-    EIG_HIP(hipEventRecord(c.evA, s1));
-    EIG_HIP(hipStreamWaitEvent(s2, c.evA, 0));
-    // ---- s1: leading half of the Cholesky factor, then the off-diagonal block U12 -------------------------
-    potrf_rec(c, s1, N, n1, 0, B, ldb, invU);
-    trsm_LUC(c, s1, n1, n2, (const T*)B, ldb, 0, B12, ldb);
-    EIG_HIP(hipEventRecord(c.evB, s1));            // U11, U12, inv blocks of U11 ready
-    // ---- s1 continues: trailing half ------------------------------------------------------------------------
-    {
-        Epi e; e.uplo = 1; e.herm_diag = 1;
-        gemm<T>(c, s1, n2, n2, n1, Tr<T>::make(-1.0, 0.0), opA('C', (const T*)B12, ldb), opB('N', (const T*)B12, ldb),
-                Tr<T>::one(), B22, ldb, e);
-    }
-    potrf_rec(c, s1, N, n2, n1, B, ldb, invU);
-    // ---- s2: the part of hegst that only needs U11 and U12 (zhegst_gpu.F90:57-101 for the leading block) ----
-    EIG_HIP(hipStreamWaitEvent(s2, c.evB, 0));
-    hegst_rec(c, s2, n1, 0, A, lda, (const T*)B, ldb);
-    trsm_LUC(c, s2, n1, n2, (const T*)B, ldb, 0, A12, lda);
-    auto hemm_half = [&]() {
-        Operand<T> up = op_plain((const T*)A, lda, 0, 0);
-        up.mask = M_UPPER;
-        Operand<T> lo = op_plain((const T*)A, lda, 1, 1);
-        lo.mask = M_SUPPER;
-        gemm<T>(c, s2, n1, n2, n1, mhalf, up, opB('N', (const T*)B12, ldb), Tr<T>::one(), A12, lda);
-        gemm<T>(c, s2, n1, n2, n1, mhalf, lo, opB('N', (const T*)B12, ldb), Tr<T>::one(), A12, lda);
-    };
-    hemm_half();
+    trsm_LUC(c, st, n1, n2, U, ldu, 0, A12, lda, c.trsm_base);
+    T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
+    const int nb32 = (n1 + 31) / 32;
+    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
+    gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
     {
         Operand<T> Ao, Bo;
-        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = B12; Ao.ld2 = ldb;
-        Bo.p = B12; Bo.ld = ldb; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
+        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
+        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
         Epi e; e.uplo = 1; e.herm_diag = 1;
-        gemm<T>(c, s2, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
     }
-    hemm_half();
-    EIG_HIP(hipEventRecord(c.evA, s2));
-    // ---- join on s1: the rest needs U22 ----------------------------------------------------------------------
-    EIG_HIP(hipStreamWaitEvent(s1, c.evA, 0));
-    trsm_RUN(c, s1, n2, n1, (const T*)B, ldb, n1, A12, lda);
-    hegst_rec(c, s1, n2, n1, A, lda, (const T*)B, ldb);
+    gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
+    EIG_HIP(hipGetLastError());
+}
+
+// Enqueues the whole factorization on c.s1 and the U11-only part of hegst on the second stream.  The caller synchronises
+// c.s1 (potrf's info), then calls hegst_pipelined_finish -- or, if the factorization failed, synchronises the second stream.
+template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
+    hipStream_t s1 = c.s1, s2 = c.second_stream();
+    const int nblk = (N + DB - 1) / DB, ngall = (N + BB - 1) / BB;
+    (void)c.scratch<T>("invU", (size_t)nblk * DB * DB);
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, 4 * sizeof(int), s1));
+    const int n1 = split_n1(N, BB);          // hegst_hybrid's own split of the top level
+    const int kb1 = n1 / DB, g1 = n1 / BB;
+    unsigned expect = 0;
+    potrf_block_rows<T>(c, s1, N, B, ldb, 0, kb1, expect);
+    build_invU_range<T>(c, s1, N, (const T*)B, ldb, 0, kb1);
+    build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, 0, g1);
+    EIG_HIP(hipEventRecord(c.evA, s1));      // U(0:n1, :) and the inverse diagonal blocks of U11 are final
+    potrf_block_rows<T>(c, s1, N, B, ldb, kb1, nblk, expect);
+    build_invU_range<T>(c, s1, N, (const T*)B, ldb, kb1, nblk - kb1);
+    build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, g1, ngall - g1);
+    EIG_HIP(hipStreamWaitEvent(s2, c.evA, 0));
+    hegst_top_part1<T>(c, s2, N, A, lda, (const T*)B, ldb, c.gst_thr, n1);
+    EIG_HIP(hipEventRecord(c.evB, s2));
+}
+
+template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, const T* U, int ldu) {
+    hipStream_t s1 = c.s1;
+    const int n1 = split_n1(N, BB), n2 = N - n1;
+    EIG_HIP(hipStreamWaitEvent(s1, c.evB, 0));
+    trsm_RUN(c, s1, n2, n1, U, ldu, n1, A + (size_t)n1 * lda, lda, c.trsm_base);
+    hegst_hybrid(c, s1, n2, n1, A, lda, U, ldu, c.gst_thr);
 }
 
 // explicit instantiations
@@ -1765,7 +1785,9 @@ template <class T> void potrf_hegst_overlapped(Ctx& c, int N, T* A, int lda, T* 
     template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \
     template void build_inv_blocks<T>(Ctx&, hipStream_t, int, const T*, int);                                            \
     template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \
-    template void potrf_hegst_overlapped<T>(Ctx&, int, T*, int, T*, int);
+    template bool pipeline_applicable<T>(const Ctx&, int);                                                               \
+    template void potrf_hegst_pipelined_begin<T>(Ctx&, int, T*, int, T*, int);                                           \
+    template void hegst_pipelined_finish<T>(Ctx&, int, T*, int, const T*, int);
 INST(double)
 INST(cplx)
 

@@ -108,7 +108,7 @@ constexpr int kTridiagDefault = 1;
 // 64-blocks whose T factors are merged pairwise (bt_build_T in evd.hip): K of the rank-k updates grows with the block.
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
-constexpr int kOverlapDefault = 0;
+constexpr int kOverlapDefault = 3;
 // Tridiagonalization: panels whose trailing order is at most this many rows take the one-launch-per-column kernel
 // (panel_col_kernel in trd.hip).  0 = never: measured in round 3, the launch it saves (4.8 us) costs more than that in
 // redundant row work -- 6.7-8.7 us per column in-kernel against 2 x 2.8 (profiles/r03_experiments.txt) -- so the two-kernel
@@ -149,9 +149,11 @@ struct Ctx {
     int hemv_balance = 0; // 1: spread the hemv tiles evenly over the rounds (measured slower, see hemv_grid in trd.hip)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
-    int overlap = kOverlapDefault;   // bit 0: potrf || first half of gst (uses the symmetric hegst recursion: -3 % latency of an
-                             // isolated solve, -15 % throughput with 2 solves in flight); bit 1: larft T factors on the second
-                             // stream while the tridiagonal eigenproblem is solved (zheevd_gpu.F90:125 overlaps the same work)
+    int in_batch = 0;        // set while this context solves one problem of a batch call with several problems in flight
+    int overlap = kOverlapDefault;   // bit 0: the latency-bound second half of potrf beside the part of hegst that only needs the
+                             // first half of the factor (potrf_hegst_pipelined_begin; only while no other solve is in flight);
+                             // bit 1: larft T factors on the second stream while the tridiagonal eigenproblem is solved
+                             // (zheevd_gpu.F90:125 overlaps the same work; measured: trd + 4 ms, off)
     struct GraphEntry {
         hipGraphExec_t exec = nullptr;
         hipGraph_t graph = nullptr;
@@ -196,6 +198,7 @@ struct StreamLease {
     StreamLease& operator=(const StreamLease&) = delete;
 };
 void copy_options(Ctx& dst, const Ctx& src);
+int streams_in_use(int dev);   // API calls in flight on the device (leased compute streams)
 int auto_batch_workers();   // 4 when the process has asked for >= 5 hardware queues (GPU_MAX_HW_QUEUES), else 3   // all tunables of src (eigsolve_set_option / environment) into dst
 
 // The library's own worker threads (context.cpp): runs fn(0) ... fn(ntasks-1) on `nworkers` of them, device `dev` current,

@@ -64,6 +64,14 @@ void return_stream(int dev, hipStream_t s) {
     for (auto& p : g_streams[dev])
         if (p.s == s) p.busy = false;
 }
+}  // namespace
+int streams_in_use(int dev) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    int n = 0;
+    for (auto& p : g_streams[dev]) n += p.busy ? 1 : 0;
+    return n;
+}
+namespace {
 
 std::mutex g_lapack_mu;
 void* g_lapack_handle = nullptr;
@@ -127,6 +135,11 @@ StreamLease::~StreamLease() {
         // nothing of this call may still be running on the stream when another context takes it (an exception may have
         // cut the call short of its final sync)
         if (c.evSync && hipEventRecord(c.evSync, c.s1) == hipSuccess) (void)hipEventSynchronize(c.evSync);
+        if (c.s2) {
+            (void)hipStreamSynchronize(c.s2);
+            return_stream(c.dev, c.s2);
+            c.s2 = nullptr;
+        }
         return_stream(c.dev, c.s1);
     }
 }
@@ -137,8 +150,12 @@ void Ctx::sync(hipStream_t st) {
     EIG_HIP(hipEventSynchronize(evSync));
 }
 
+// The second stream of a call is LEASED from the same pool as its first one (and handed back when the call returns): the pool's
+// streams are created once, in order, and map to distinct hardware queues / pipes (profiles/r03_experiments.txt 5, 10, 14).  A
+// private per-context stream -- created whenever a solve first overlaps two chains -- stays behind idle, takes a hardware queue
+// out of that order, and a later batch finds two of its launch chains on one pipe: 16.4 -> 11 problems/s at C3 (measured).
 hipStream_t Ctx::second_stream() {
-    if (!s2) EIG_HIP(hipStreamCreate(&s2));
+    if (!s2) s2 = lease_stream(dev, nullptr);
     return s2;
 }
 
@@ -172,7 +189,7 @@ void Ctx::release() {
     if (evSync) (void)hipEventDestroy(evSync);
     evSync = nullptr;
     // s1 belongs to the stream pool: never destroyed
-    if (s2) (void)hipStreamDestroy(s2);
+    if (s2) return_stream(dev, s2);   // (pool streams live until eigsolve_finalize)
     for (auto& e : ev) e = nullptr;
     evA = evB = nullptr; d_info = nullptr; h_info = nullptr; s1 = s2 = nullptr;
     if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);

@@ -331,20 +331,21 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     }
     // larft T factors depend only on the reflectors: build them on the second stream while the tridiagonal
     // eigenproblem is being solved (zheevd_gpu.F90:125 does the same per block with stream1/stream2)
-    const bool ovT = (c.overlap & 2) != 0;
-    hipStream_t stT = ovT ? c.second_stream() : st;
-    if (ovT) {
-        EIG_HIP(hipEventRecord(c.evA, st));
-        EIG_HIP(hipStreamWaitEvent(stT, c.evA, 0));
+    // Only for a solve that has the device to itself, and only ENQUEUED once the tridiagonalization has finished: a queue that sits
+    // blocked on an event while the per-column kernels run costs every one of their dispatches ~1 us (measured: trd + 4.7 ms).
+    const bool ovT = (c.overlap & 2) != 0 && !c.in_batch && streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
+    auto build_T_beside = [&]() {
+        hipStream_t stT = c.second_stream();
         bt_build_T<T>(c, stT, N, Vsrc, ldv, tau_bt, c.bt_nb);
         EIG_HIP(hipEventRecord(c.evB, stT));
-    }
+    };
     {
     PhaseRange stedc_range(Tr<T>::cx ? "zstedc" : "dstedc");   // zheevd_gpu.F90:100
     if (c.tridiag_device) {
         // device-side divide & conquer: no N x N host round trip at all
         c.sync(st);
         pt.collect(PH_TRD);
+        if (ovT) build_T_beside();
         double t0 = now_ms();
         double* Qd = nullptr;
         int ldq_d = 0;
@@ -366,6 +367,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     if (N > 1) EIG_HIP(hipMemcpyAsync(e_h, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
     c.sync(st);
     pt.collect(PH_TRD);
+    if (ovT) build_T_beside();
     double t0 = now_ms();
     stedc_fn f = get_dstedc();
     if (!f) {
@@ -414,34 +416,22 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     clear_phases(c);
     double t_all = now_ms();
     const int m = iu - il + 1;
-    if (c.overlap) {
-        // potrf || leading half of gst on two streams (both are chains of small dependent launches); phase
-        // times: "potrf" = until the factor is complete, "gst" = the non-overlapped remainder.
-        pt.begin(PH_POTRF);
-        potrf_hegst_overlapped<T>(c, N, A, lda, B, ldb);
-        pt.end(PH_POTRF);
-        EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-        c.sync(st);
-        pt.collect(PH_POTRF);
-        if (c.h_info[0] != 0) {
-            printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
-            return -1;
-        }
-        pt.begin(PH_GST);
-        build_inv_blocks<T>(c, st, N, (const T*)B, ldb);   // for the final trsm
-        pt.end(PH_GST);
-    } else {
+    // potrf || the U11-only part of hegst (blas3.hip: potrf_hegst_pipelined_begin) when this solve has the device to itself;
+    // phase times: "potrf" = until the factor is complete, "gst" = what is left of hegst after that.
+    const bool pipe = (c.overlap & 1) && !c.in_batch && pipeline_applicable<T>(c, N) && streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
     {
         PhaseRange r(Tr<T>::cx ? "cusolverdnZpotrf" : "cusolverdnDpotrf");   // the reference's range name, :134
         pt.begin(PH_POTRF);
-        potrf_upper<T>(c, st, N, B, ldb);
+        if (pipe) potrf_hegst_pipelined_begin<T>(c, N, A, lda, B, ldb);
+        else potrf_upper<T>(c, st, N, B, ldb);
         pt.end(PH_POTRF);
     }
     EIG_HIP(hipMemcpyAsync(c.h_info, c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
     c.sync(st);
     pt.collect(PH_POTRF);
     if (c.h_info[0] != 0) {
+        if (pipe) c.sync(c.second_stream());   // (the part of hegst already queued works on A)
         if (c.h_info[0] < 0) printf(" %s error: potrf failed! (the block-row kernel could not synchronise its workgroups; use option potrf = 0)\n", name);
         else printf(" %s error: potrf failed! (B is not positive definite, pivot %d)\n", name, c.h_info[0]);
         return -1;
@@ -451,9 +441,9 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     {
         PhaseRange r(Tr<T>::cx ? "zhegst_gpu" : "dsygst_gpu");   // :155
         pt.begin(PH_GST);   // (potrf_upper has merged the inverse diagonal blocks already)
-        hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
+        if (pipe) hegst_pipelined_finish<T>(c, N, A, lda, (const T*)B, ldb);
+        else hegst_upper<T>(c, st, N, A, lda, B, ldb);  // :156-158
         pt.end(PH_GST);
-    }
     }
     int info;
     {
@@ -575,10 +565,13 @@ static int hegvdx_batch_workers(Ctx& c0, int nprob, int N, T* const* A, int lda,
                                 T* const* Z_h, int ldz_h, int skip_host_copy, int* infos, const char* name) {
     clear_phases(c0);
     const double t_all = now_ms();
-    batch_run(c0.dev, c0.batch_workers < 0 ? auto_batch_workers() : c0.batch_workers, nprob, [&](int q) {
+    const int nworkers = c0.batch_workers < 0 ? auto_batch_workers() : c0.batch_workers;
+    const int several = nprob > 1 && nworkers > 1;
+    batch_run(c0.dev, nworkers, nprob, [&](int q) {
         guarded(&infos[q], [&]() -> int {
             Ctx& c = ctx();
             copy_options(c, c0);
+            struct InBatch { Ctx& c; explicit InBatch(Ctx& c_, int v) : c(c_) { c.in_batch = v; } ~InBatch() { c.in_batch = 0; } } ib(c, several);
             return hegvdx_core<T>(c, N, A[q], lda, B[q], ldb, Z[q], ldz, il, iu, w_d[q], e_d[q], tau_d[q], W_d[q], w_h[q], nullptr,
                                   nullptr, N, nullptr, 0, nullptr, 0, Z_h ? Z_h[q] : nullptr, ldz_h, skip_host_copy, name);
         });

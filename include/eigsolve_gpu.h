@@ -45,10 +45,12 @@ int eigsolve_set_host_threads(int nthreads);
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
  * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
  * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
- * "overlap": bit mask of independent launch chains of one solve that run on a second stream: bit 0 = second half of
- * potrf with the first half of gst, bit 1 = larft T factors with the tridiagonal eigensolver (zheevd_gpu.F90:125
- * overlaps the same work).  Measured on MI355X: once a context drives two hardware queues every dependent launch
- * gets slower (bit 1 alone: back-transform -1.1 ms, whole solve +13 ms), so 0 (default) = single stream.
+ * "overlap": bit mask of independent launch chains of one solve that run on a second stream (leased from the library's stream
+ * pool for the call): bit 0 = the latency-bound second half of potrf beside the part of hegst that only needs the first half
+ * of the factor, bit 1 = larft T factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work).
+ * Default 3.  Same kernels, operands and order of operations per block: results are bit-identical to "overlap" 0.  Only
+ * applied to a solve that has the device to itself (no other call of this library in flight, not inside a batch call):
+ * C3 isolated solve 95.7 -> 94.0 ms.
  * "bt_nb": reflectors per block of the back-transformation: 64 (the reference's larfb width), 128, 256 (default) or 512 --
  * 64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
  * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default automatic: 4 when the process allows
@@ -63,7 +65,8 @@ int eigsolve_set_host_threads(int nthreads);
  * loop (zhegst_gpu.F90:51-107) with nb = "trsm_base"; "trsm_base" also accepts 512 / 1024 (inverse blocks merged on MFMA).
  * "real_il_reference": 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
  * (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).
- * "p_wt", "hemv_balance": measured-and-rejected variants of the panel mat-vec kernel (off).
+ * "p_wt", "hemv_balance" (k: spread the mat-vec tiles evenly when they make >= k rounds): measured-and-rejected variants of the
+ * panel mat-vec kernel (off).
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 
