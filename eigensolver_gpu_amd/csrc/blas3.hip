@@ -975,9 +975,11 @@ __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, i
 // The diagonal block is factored IN PLACE by workgroup 0 while the other workgroups read the original block: workgroup 0
 // only stores U_kk once every other workgroup has announced (one agent-scope atomic on `loaded`, a cumulative counter
 // of the current factorization) that its copy sits in registers.  Nobody waits for workgroup 0, so the spin cannot deadlock.
+// (7 waves per SIMD = 72 VGPRs: the sixteen waves of a block-row workgroup then fit on a CU beside ONE 224-VGPR product workgroup
+// of the overlapped hegst chain instead of needing a completely empty CU -- potrf || hegst pipeline below)
 template <class T>
-__global__ void __launch_bounds__(DGT) chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info, unsigned* loaded,
-                                                       unsigned expect) {
+__global__ void __launch_bounds__(DGT) __attribute__((amdgpu_waves_per_eu(7, 7)))
+chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info, unsigned* loaded, unsigned expect) {
     __shared__ T rowb[2][DB];   // pivot row of the diagonal block
     __shared__ T rowp[2][DB];   // pivot row of this workgroup's chunk
     const int tid = threadIdx.x;
@@ -1564,7 +1566,20 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
 
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
-template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr);
+// hegst on a stream of its own, released stage by stage as block rows of the factor complete on the factorization's stream
+// (potrf || hegst pipeline below): need(r) = "the next operation reads rows < r of U (and their inverse diagonal blocks)".
+constexpr int kStageRows = 1024;
+struct UGate {
+    hipStream_t st;
+    hipEvent_t* ev;
+    int have;
+    void need(int rows) {
+        const int s_ = (rows + kStageRows - 1) / kStageRows;
+        while (have < s_) EIG_HIP(hipStreamWaitEvent(st, ev[have++], 0));
+    }
+};
+template <class T>
+static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr, UGate* gate = nullptr);
 template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
@@ -1631,20 +1646,23 @@ template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, in
 
 // One level of the symmetric algorithm (zhegst_gpu.F90:51-107 with the block size = half the matrix): every
 // operation is a large MFMA launch.  Diagonal blocks of order <= thr fall back to the two-solve form.
-template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr) {
+template <class T>
+static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr, UGate* gate) {
     if (n <= 0) return;
     const int gran = norm_base(c.trsm_base);
     if (n <= thr || n <= gran) {
+        if (gate) gate->need(k0 + n);
         hegst_two_solves_at(c, st, n, k0, A, lda, U, ldu);
         return;
     }
     int n1 = split_n1(n, gran), n2 = n - n1;   // block boundaries must match the inverse diagonal blocks
-    hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr);
+    hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr, gate);
     T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
     T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
     T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
     const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
     const T mhalf = Tr<T>::make(-0.5, 0.0);
+    if (gate) gate->need(k0 + n1);                                     // the next four steps read U(k0 : k0+n1, :) only
     trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda, c.trsm_base);        // A12 <- U11^-H A12
     // Herm(A11) completed once into scratch: the two hemm steps are then plain full-rate gemms
     T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
@@ -1664,8 +1682,9 @@ template <class T> static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k
         gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
     }
     hemm_half();
+    if (gate) gate->need(k0 + n);                                      // U22 from here on
     trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda, c.trsm_base);  // A12 <- A12 U22^-1
-    hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr);
+    hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr, gate);
 }
 
 // The reference's own loop (zhegst_gpu.F90:51-107) with block size nb = the order of the inverse diagonal blocks
@@ -1702,71 +1721,48 @@ template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A
 }
 
 // ---- potrf || hegst pipeline (option "overlap" bit 0) ----------------------------------------------------------------
-// The second half of the block-row Cholesky is a chain of small launches (64 workgroups per block-row kernel, short rank-64
-// updates: 2 ms at C3 with most of the chip idle), and most of hegst's top level only needs the FIRST half of the factor:
-//     hegst(A11, U11),  A12 <- U11^-H A12,  A12 -= 1/2 Herm(A11) U12,  A22 -= A12^H U12 + U12^H A12,  A12 -= 1/2 Herm(A11) U12
-// (zhegst_gpu.F90:57-101 with the block = the leading half).  So: block rows of the leading half on the call's stream, then
-// the rest of the factorization on that stream WHILE the second (low-priority) stream runs those hegst steps; after the join
-// the two steps that need U22 (A12 <- A12 U22^-1, hegst(A22, U22)).  Same kernels, same operands, same order of operations
-// on every block as the sequential path: results are bit-identical.  Only used for a solve that has the device to itself
-// (the caller checks the stream pool): with several solves in flight the chip is full anyway and every extra stream costs
-// a hardware queue (profiles/r03_experiments.txt 5, 10).
+// The block-row Cholesky is a chain of launches that leave most of the chip idle (64 x 42 us block-row kernels of <= 64
+// workgroups; short rank-64 updates in its second half), and hegst needs the factor only progressively: with the half-split
+// recursion every step reads U(0 : r, :) for a bound r that grows as the recursion moves down the diagonal (hegst_hybrid's
+// gate->need(r) calls).  So: the factorization on the call's stream, in stages of 1024 rows (block rows + the inverse diagonal
+// blocks of the stage, then an event); hegst as a whole on the second stream, each step waiting for the stage event it needs.
+// Same kernels, same operands, same order of operations on every block as the one-stream path: results are bit-identical.
+// Only for a solve that has the device to itself (the caller checks): with several solves in flight the chip is full anyway and
+// every additional active queue costs the others (profiles/r03_experiments.txt 5, 10, 14).
 template <class T> bool pipeline_applicable(const Ctx& c, int N) {
-    return c.gst_mode == 2 && c.potrf_mode != 0 && norm_base(c.trsm_base) == BB && N > c.gst_thr && N >= 2 * BB;
+    return c.gst_mode == 2 && c.potrf_mode != 0 && norm_base(c.trsm_base) == BB && N > c.gst_thr && N >= 2 * BB &&
+           (N + kStageRows - 1) / kStageRows <= 16;
 }
 
-template <class T> static void hegst_top_part1(Ctx& c, hipStream_t st, int n, T* A, int lda, const T* U, int ldu, int thr, int n1) {
-    const int n2 = n - n1;
-    hegst_hybrid(c, st, n1, 0, A, lda, U, ldu, thr);
-    T* A11 = A;
-    T* A12 = A + (size_t)n1 * lda;
-    T* A22 = A + (size_t)n1 + (size_t)n1 * lda;
-    const T* U12 = U + (size_t)n1 * ldu;
-    const T mhalf = Tr<T>::make(-0.5, 0.0);
-    trsm_LUC(c, st, n1, n2, U, ldu, 0, A12, lda, c.trsm_base);
-    T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
-    const int nb32 = (n1 + 31) / 32;
-    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
-    gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
-    {
-        Operand<T> Ao, Bo;
-        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
-        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
-        Epi e; e.uplo = 1; e.herm_diag = 1;
-        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
-    }
-    gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
-    EIG_HIP(hipGetLastError());
-}
-
-// Enqueues the whole factorization on c.s1 and the U11-only part of hegst on the second stream.  The caller synchronises
-// c.s1 (potrf's info), then calls hegst_pipelined_finish -- or, if the factorization failed, synchronises the second stream.
+// Enqueues the whole factorization on c.s1 and the whole of hegst, gated, on the second stream.  The caller synchronises c.s1
+// (potrf's info -- every stage event is recorded whether or not the factorization fails), then calls hegst_pipelined_finish,
+// or, on failure, synchronises the second stream.
 template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda, T* B, int ldb) {
-    hipStream_t s1 = c.s1, s2 = c.second_stream();
+    hipStream_t s1 = c.s1;
     const int nblk = (N + DB - 1) / DB, ngall = (N + BB - 1) / BB;
+    const int nstage = (N + kStageRows - 1) / kStageRows;
     (void)c.scratch<T>("invU", (size_t)nblk * DB * DB);
+    for (int s_ = 0; s_ < nstage; ++s_)
+        if (!c.evStage[s_]) EIG_HIP(hipEventCreateWithFlags(&c.evStage[s_], hipEventDisableTiming));
     EIG_HIP(hipMemsetAsync(c.d_info, 0, 4 * sizeof(int), s1));
-    const int n1 = split_n1(N, BB);          // hegst_hybrid's own split of the top level
-    const int kb1 = n1 / DB, g1 = n1 / BB;
     unsigned expect = 0;
-    potrf_block_rows<T>(c, s1, N, B, ldb, 0, kb1, expect);
-    build_invU_range<T>(c, s1, N, (const T*)B, ldb, 0, kb1);
-    build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, 0, g1);
-    EIG_HIP(hipEventRecord(c.evA, s1));      // U(0:n1, :) and the inverse diagonal blocks of U11 are final
-    potrf_block_rows<T>(c, s1, N, B, ldb, kb1, nblk, expect);
-    build_invU_range<T>(c, s1, N, (const T*)B, ldb, kb1, nblk - kb1);
-    build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, g1, ngall - g1);
-    EIG_HIP(hipStreamWaitEvent(s2, c.evA, 0));
-    hegst_top_part1<T>(c, s2, N, A, lda, (const T*)B, ldb, c.gst_thr, n1);
+    constexpr int SB = kStageRows / DB, SG = kStageRows / BB;
+    for (int s_ = 0; s_ < nstage; ++s_) {
+        const int kb0 = s_ * SB, kb1 = min(nblk, kb0 + SB), g0 = s_ * SG, g1 = min(ngall, g0 + SG);
+        potrf_block_rows<T>(c, s1, N, B, ldb, kb0, kb1, expect);
+        build_invU_range<T>(c, s1, N, (const T*)B, ldb, kb0, kb1 - kb0);
+        build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, g0, g1 - g0);
+        EIG_HIP(hipEventRecord(c.evStage[s_], s1));   // rows < (s_+1) * 1024 of U and their inverse diagonal blocks are final
+    }
+    // (everything above is queued before the first wait below is: a wait on an event that has not been recorded yet is a no-op)
+    hipStream_t s2 = c.second_stream();
+    UGate gate{s2, c.evStage, 0};
+    hegst_hybrid<T>(c, s2, N, 0, A, lda, (const T*)B, ldb, c.gst_thr, &gate);
     EIG_HIP(hipEventRecord(c.evB, s2));
 }
 
 template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, const T* U, int ldu) {
-    hipStream_t s1 = c.s1;
-    const int n1 = split_n1(N, BB), n2 = N - n1;
-    EIG_HIP(hipStreamWaitEvent(s1, c.evB, 0));
-    trsm_RUN(c, s1, n2, n1, U, ldu, n1, A + (size_t)n1 * lda, lda, c.trsm_base);
-    hegst_hybrid(c, s1, n2, n1, A, lda, U, ldu, c.gst_thr);
+    EIG_HIP(hipStreamWaitEvent(c.s1, c.evB, 0));
 }
 
 // explicit instantiations

@@ -135,6 +135,7 @@ struct Ctx {
     hipEvent_t evSync = nullptr;
     hipEvent_t ev[2 * PH_COUNT] = {};
     hipEvent_t evA = nullptr, evB = nullptr;
+    hipEvent_t evStage[16] = {};   // block-row stages of the factorization (potrf || hegst pipeline), created on first use
     std::map<std::string, std::pair<void*, size_t>> slots;  // named grow-only device scratch
     std::map<std::string, std::pair<void*, size_t>> hslots; // named grow-only pinned host scratch
     int* d_info = nullptr;   // device int (replaces devInfo_d)

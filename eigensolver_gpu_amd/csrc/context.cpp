@@ -183,6 +183,7 @@ void Ctx::release() {
     for (auto& e : ev)
         if (e) (void)hipEventDestroy(e);
     if (evA) (void)hipEventDestroy(evA);
+    for (auto& e : evStage) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (evB) (void)hipEventDestroy(evB);
     if (d_info) (void)hipFree(d_info);
     if (h_info) (void)hipHostFree(h_info);
