@@ -23,7 +23,9 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
 #include "stedc.h"
+#include "lanes.h"
 
 namespace eig {
 
@@ -37,7 +39,8 @@ constexpr int MAXK_LDS = 4096;  // poles staged in LDS per merge (larger merges 
 // accessed uniformly through shuffles; lane r owns row r of the eigenvector block (LDS, no cross-lane
 // traffic).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double lane_get(double v, int idx) { return __shfl(v, idx); }
+// (the index is wave-uniform everywhere below: v_readlane with a scalar lane select, not a ds_bpermute round trip)
+__device__ __forceinline__ double lane_get(double v, int idx) { return read_lane(v, __builtin_amdgcn_readfirstlane(idx)); }
 
 __global__ void __launch_bounds__(64) dc_leaf_kernel(const int* leaf_off, const int* leaf_n, const double* dmod, const double* e,
                                                      double* D, double* Q, int ldq, int* info) {
@@ -69,7 +72,10 @@ __global__ void __launch_bounds__(64) dc_leaf_kernel(const int* leaf_off, const 
             for (i = m - 1; i >= l; --i) {
                 double ei = lane_get(er, i);
                 double f = s * ei, b = c * ei;
-                r = hypot(f, g);
+                // the matrix is scaled to unit max-norm: f*f + g*g cannot overflow, and an underflow to 0 takes the r == 0 branch
+                // (tql2's own treatment of a vanished rotation); v_sqrt / v_rcp + Newton instead of hypot() and two divisions --
+                // this loop is one long dependency chain, ~2000 rotations per leaf
+                r = fast_sqrt(fma(f, f, g * g));
                 if (lane == i + 1) er = r;
                 if (r == 0.0) {
                     if (lane == i + 1) dr -= p;
@@ -77,7 +83,8 @@ __global__ void __launch_bounds__(64) dc_leaf_kernel(const int* leaf_off, const 
                     early = true;
                     break;
                 }
-                s = f / r; c = g / r;
+                const double rinv = fast_rcp(r);
+                s = f * rinv; c = g * rinv;
                 g = lane_get(dr, i + 1) - p;
                 r = (lane_get(dr, i) - g) * s + 2.0 * c * b;
                 p = s * r;
@@ -441,6 +448,7 @@ struct Node {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+static double now_ms_dc() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double* e_d, double* w_d, double** Q_out, int* ldq_out, int il, int iu) {
     if (N <= 0) return 0;
     // ---- host copies of d, e; scaling; tree; torn diagonal ------------------------------------
@@ -599,10 +607,13 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
                            (const int*)(d_zrow_all + (size_t)level * N), (const double*)(d_zscale_all + (size_t)level * N),
                            (const double*)Dcur, d_z);
         EIG_HIP(hipMemcpyAsync(h_zD, d_z, sizeof(double) * 2 * (size_t)N, hipMemcpyDeviceToHost, st));
+        const double tq0 = now_ms_dc();
         c.sync(st);
+        const double tq1 = now_ms_dc();
 
         // ---- deflation scan per merge (host, sequential in j; LAPACK dlaed2's logic) ----
         h_md.clear();
+        static thread_local std::vector<int> perm, permtmp, coltyp, nondef, defl;   // (reused: no allocation per merge)
         int rot_total = 0, nmax = 0, kmax = 0;
         for (int id : ms) {
             const Node& nd = nodes[id];
@@ -613,15 +624,25 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
             m.rot_off = rot_total;
             double* dd = &hD[off];
             double* zz = &hz[off];
-            std::vector<int> perm(n);
+            // ascending order of the poles, ties by index (= a stable sort of 0..n-1 by dd).  The two halves are the children's
+            // eigenvalue lists, which the previous level left ascending: one linear merge (LAPACK's dlamrg step) instead of a
+            // sort; anything else (a leaf order that is not ascending) falls back to the sort.
+            perm.resize(n);
             for (int i = 0; i < n; ++i) perm[i] = i;
-            std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return dd[a] < dd[b]; });
+            auto by_dd = [&](int a, int b) { return dd[a] < dd[b]; };
+            if (std::is_sorted(dd, dd + n1) && std::is_sorted(dd + n1, dd + n)) {
+                permtmp.resize(n);
+                std::merge(perm.begin(), perm.begin() + n1, perm.begin() + n1, perm.end(), permtmp.begin(), by_dd);
+                perm.swap(permtmp);
+            } else {
+                std::stable_sort(perm.begin(), perm.end(), by_dd);
+            }
             double dmax = 0.0, zmax = 0.0;
             for (int i = 0; i < n; ++i) { dmax = std::max(dmax, std::fabs(dd[i])); zmax = std::max(zmax, std::fabs(zz[i])); }
             const double tol = 8.0 * EPSD * std::max(dmax, zmax);
-            std::vector<int> coltyp(n);
+            coltyp.resize(n);
             for (int i = 0; i < n; ++i) coltyp[i] = (i < n1) ? 1 : 3;
-            std::vector<int> nondef, defl;
+            nondef.clear(); defl.clear();
             if (m.rho * zmax <= tol) {
                 for (int t = 0; t < n; ++t) defl.push_back(perm[t]);
             } else {
@@ -671,7 +692,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
                 h_w[off + t] = zz[j];
             }
             // deflated, ascending by (possibly rotated) value
-            std::stable_sort(defl.begin(), defl.end(), [&](int a, int b) { return dd[a] < dd[b]; });
+            if (!std::is_sorted(defl.begin(), defl.end(), by_dd)) std::stable_sort(defl.begin(), defl.end(), by_dd);
             for (int u = 0; u < (int)defl.size(); ++u) {
                 h_dcol[off + u] = off + defl[u];
                 h_dval[off + u] = dd[defl[u]];
@@ -682,6 +703,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
         }
         const int nm = (int)h_md.size();
         for (int q = 0; q < nm; ++q) h_mdp[q] = h_md[q];
+        if (getenv("EIGSOLVE_DC_TIMING")) printf("dc level %d: %d merges, wait %.3f ms, host scan %.3f ms\n", level, nm, tq1 - tq0, now_ms_dc() - tq1);
         EIG_HIP(hipMemcpyAsync(d_pack, h_pack, pack_bytes, hipMemcpyHostToDevice, st));
         if (rot_total > 0) {
             hipLaunchKernelGGL(dc_rotate_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const int*)d_rp,
