@@ -12,10 +12,13 @@ python $R/tools/rocpd_stats.py $(find /tmp/kt -name "*.db" | head -1) $O/r03_c3_
 # (2) C2: dsygvdx N=2048 m=512
 rm -rf /tmp/kt2; rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o c2 -- python $R/bench.py --real --n 2048 --no-c5 --no-cpu-baseline --no-host-tridiag > $O/bench_c2_traced.json 2> $O/bench_c2_traced.err
 python $R/tools/rocpd_stats.py $(find /tmp/kt2 -name "*.db" | head -1) $O/r03_c2_kernel_stats.txt > /dev/null
-# (3) phase-segmented traces of one isolated solve
-rm -rf /tmp/tr; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr -o c3 -- python $R/tools/solve_trace.py 4096 1024 1 > $O/trace_c3.log 2>&1
-python $R/tools/trace_phases.py $(find /tmp/tr -name "*.db" | head -1) --list potrf,bt,trsm $O/r03_phase_trace_c3.txt > /dev/null
-rm -rf /tmp/tr2; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr2 -o c2 -- python $R/tools/solve_trace.py 2048 512 1 real > $O/trace_c2.log 2>&1
+# (3) phase-segmented traces of one isolated solve: on ONE stream (EIGSOLVE_OVERLAP=0: every kernel belongs to exactly one phase) and
+#     in the default form (hegst beside potrf, T factors beside the tridiagonal solver: sections are spans of overlapped chains)
+rm -rf /tmp/tr; EIGSOLVE_OVERLAP=0 EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr -o c3 -- python $R/tools/solve_trace.py 4096 1024 1 > $O/trace_c3.log 2>&1
+python $R/tools/trace_phases.py $(find /tmp/tr -name "*.db" | head -1) --list potrf,gst,bt,trsm $O/r03_phase_trace_c3.txt > /dev/null
+rm -rf /tmp/tr3; EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr3 -o c3p -- python $R/tools/solve_trace.py 4096 1024 1 > $O/trace_c3_pipelined.log 2>&1
+python $R/tools/trace_phases.py $(find /tmp/tr3 -name "*.db" | head -1) $O/r03_phase_trace_c3_pipelined.txt > /dev/null
+rm -rf /tmp/tr2; EIGSOLVE_OVERLAP=0 EIGSOLVE_TRACE_MARKS=1 rocprofv3 --kernel-trace -d /tmp/tr2 -o c2 -- python $R/tools/solve_trace.py 2048 512 1 real > $O/trace_c2.log 2>&1
 python $R/tools/trace_phases.py $(find /tmp/tr2 -name "*.db" | head -1) $O/r03_phase_trace_c2.txt > /dev/null
 # (4) counters (bounded: counter collection serialises every dispatch)
 cd $R; timeout 600 bash tools/pmc_collect.sh gpurun_out/r03_pmc $O/r03_pmc_summary.txt $O/r03_hemv_traffic.json
