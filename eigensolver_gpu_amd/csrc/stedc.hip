@@ -451,18 +451,21 @@ struct Node {
 static double now_ms_dc() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double* e_d, double* w_d, double** Q_out, int* ldq_out, int il, int iu) {
     if (N <= 0) return 0;
-    // ---- host copies of d, e; scaling; tree; torn diagonal ------------------------------------
-    std::vector<double> d(N), e(N > 1 ? N - 1 : 1, 0.0);
-    EIG_HIP(hipMemcpyAsync(d.data(), d_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
-    if (N > 1) EIG_HIP(hipMemcpyAsync(e.data(), e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
-    c.sync(st);
-    double orgnrm = 0.0;
-    for (int i = 0; i < N; ++i) orgnrm = std::max(orgnrm, std::fabs(d[i]));
-    for (int i = 0; i + 1 < N; ++i) orgnrm = std::max(orgnrm, std::fabs(e[i]));
-    if (!(orgnrm > 0.0) || !std::isfinite(orgnrm)) orgnrm = 1.0;
-    const double sc = 1.0 / orgnrm;
-    for (int i = 0; i < N; ++i) d[i] *= sc;
-    for (int i = 0; i + 1 < N; ++i) e[i] *= sc;
+    // ---- host copies of d, e (pinned: truly asynchronous), behind the two N x N memsets the merge levels need: the device
+    //      zeroes Qa / Qb (0.1 ms at C3) while the host builds the tree ------------------------------------------------
+    const size_t NN = (size_t)N * N;
+    double* Qa = c.scratch<double>("dc_Qa", NN);
+    double* Qb = c.scratch<double>("dc_Qb", NN);
+    EIG_HIP(hipMemsetAsync(Qa, 0, NN * sizeof(double), st));
+    EIG_HIP(hipMemsetAsync(Qb, 0, NN * sizeof(double), st));
+    EIG_HIP(hipMemsetAsync(c.d_info + 1, 0, sizeof(int), st));
+    double* h_de = reinterpret_cast<double*>(c.host_scratch_bytes("dc_de_h", sizeof(double) * 3 * (size_t)N + 64));
+    double* d = h_de;
+    double* e = h_de + N;
+    double* dmod = h_de + 2 * (size_t)N;
+    EIG_HIP(hipMemcpyAsync(d, d_d, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    if (N > 1) EIG_HIP(hipMemcpyAsync(e, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
+    else e[0] = 0.0;
 
     std::vector<Node> nodes;
     std::vector<int> leaves;
@@ -483,8 +486,16 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     };
     const int root = build(0, N);
     const int nlevels = nodes[root].level;
+    c.sync(st);
+    double orgnrm = 0.0;
+    for (int i = 0; i < N; ++i) orgnrm = std::max(orgnrm, std::fabs(d[i]));
+    for (int i = 0; i + 1 < N; ++i) orgnrm = std::max(orgnrm, std::fabs(e[i]));
+    if (!(orgnrm > 0.0) || !std::isfinite(orgnrm)) orgnrm = 1.0;
+    const double sc = 1.0 / orgnrm;
+    for (int i = 0; i < N; ++i) d[i] *= sc;
+    for (int i = 0; i + 1 < N; ++i) e[i] *= sc;
     // tear: every internal node's cut modifies the two diagonal entries next to it
-    std::vector<double> dmod = d;
+    for (int i = 0; i < N; ++i) dmod[i] = d[i];
     for (const Node& nd : nodes)
         if (nd.left >= 0) {
             int cut = nodes[nd.right].off;  // first index of the right child
@@ -494,10 +505,7 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
         }
 
     // ---- device buffers ------------------------------------------------------------------------------
-    const size_t NN = (size_t)N * N;
     const int ldq = N;
-    double* Qa = c.scratch<double>("dc_Qa", NN);
-    double* Qb = c.scratch<double>("dc_Qb", NN);
     double* Qg = c.scratch<double>("dc_Qg", NN);
     double* S = c.scratch<double>("dc_S", NN);    // delta matrix, later reused as Qtmp
     double* S2 = c.scratch<double>("dc_S2", NN);
@@ -536,19 +544,16 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
     if (il < 1) il = 1;
     int* d_info = c.d_info + 1;
 
-    EIG_HIP(hipMemsetAsync(Qa, 0, NN * sizeof(double), st));
-    EIG_HIP(hipMemsetAsync(Qb, 0, NN * sizeof(double), st));
-    EIG_HIP(hipMemsetAsync(d_info, 0, sizeof(int), st));
-    EIG_HIP(hipMemcpyAsync(d_dmod, dmod.data(), sizeof(double) * N, hipMemcpyHostToDevice, st));
-    EIG_HIP(hipMemcpyAsync(d_e, e.data(), sizeof(double) * e.size(), hipMemcpyHostToDevice, st));
+    EIG_HIP(hipMemcpyAsync(d_dmod, dmod, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    EIG_HIP(hipMemcpyAsync(d_e, e, sizeof(double) * (N > 1 ? N - 1 : 1), hipMemcpyHostToDevice, st));
 
     // ---- leaves ------------------------------------------------------------------------------------------
     {
-        std::vector<int> lo(leaves.size()), ln(leaves.size());
+        int* lo = reinterpret_cast<int*>(c.host_scratch_bytes("dc_leaf_h", sizeof(int) * 2 * (size_t)N + 64));   // pinned, persistent
+        int* ln = lo + N;
         for (size_t i = 0; i < leaves.size(); ++i) { lo[i] = nodes[leaves[i]].off; ln[i] = nodes[leaves[i]].n; }
-        EIG_HIP(hipMemcpyAsync(d_leafoff, lo.data(), sizeof(int) * lo.size(), hipMemcpyHostToDevice, st));
-        EIG_HIP(hipMemcpyAsync(d_leafn, ln.data(), sizeof(int) * ln.size(), hipMemcpyHostToDevice, st));
-        c.sync(st);  // lo/ln are stack vectors
+        EIG_HIP(hipMemcpyAsync(d_leafoff, lo, sizeof(int) * leaves.size(), hipMemcpyHostToDevice, st));
+        EIG_HIP(hipMemcpyAsync(d_leafn, ln, sizeof(int) * leaves.size(), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, (const int*)d_leafoff, (const int*)d_leafn,
                            (const double*)d_dmod, (const double*)d_e, Da, Qa, ldq, d_info);
         EIG_HIP(hipGetLastError());
