@@ -190,7 +190,7 @@ def main():
             wss[key] = api.Workspace(nn, cplx)
         return wss[key]
 
-    c5_fuse = 8
+    c5_fuse = 16
     fuse = args.fuse if args.fuse > 0 else (c5_fuse if args.workload == "c5" else max(1, args.batch))
 
     # ---- the batch of one step: total problems and this rank's share ----------------------------------------------

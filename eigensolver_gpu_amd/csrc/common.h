@@ -168,6 +168,8 @@ struct Ctx {
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
     int trd_fuse = -1;       // >= 0: order below which panels use panel_col_kernel (0 = never); -1 = default per type
+    int batch_fuse = -1;     // problems per launch chain of a batch call that share the per-column launches of the tridiagonalization
+                             // (lockstep groups of <= 4): -1 = automatic (groups while a matrix is <= 96 MiB), 1 = none
     int batch_workers = -1;  // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
                              // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip);
                              // -1 = automatic, see auto_batch_workers()

@@ -210,7 +210,7 @@ void copy_options(Ctx& c, const Ctx& d) {
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
-    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.trd_fuse = d.trd_fuse;
+    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.trd_fuse = d.trd_fuse; c.batch_fuse = d.batch_fuse;
 }
 
 // ---- the library's worker threads ------------------------------------------------------------------------------------
@@ -325,6 +325,9 @@ static void init_options(Ctx& c) {
     if (const char* e = getenv("EIGSOLVE_TRD_FUSE")) c.trd_fuse = atoi(e);
     if (c.trd_fuse > 8192) c.trd_fuse = 8192;
     if (const char* e = getenv("EIGSOLVE_BATCH_WORKERS")) c.batch_workers = atoi(e);
+    c.batch_fuse = d.batch_fuse;
+    if (const char* e = getenv("EIGSOLVE_BATCH_FUSE")) c.batch_fuse = atoi(e);
+    if (c.batch_fuse < -1 || c.batch_fuse == 0 || c.batch_fuse > 4) c.batch_fuse = -1;
     if (c.batch_workers < -1 || c.batch_workers > 16) c.batch_workers = d.batch_workers;
     if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
     if (const char* e = getenv("EIGSOLVE_TRACE_MARKS")) c.trace_marks = atoi(e) != 0;
@@ -521,6 +524,7 @@ int eigsolve_set_option(const char* name, int value) {
         else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
         else if (s == "trd_fuse") { c.trd_fuse = value < 0 ? -1 : (value > 8192 ? 8192 : value); c.drop_graphs(); }
         else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;
+        else if (s == "batch_fuse") c.batch_fuse = (value < 1 || value > 4) ? -1 : value;
         else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
         else return -1;
         return 0;

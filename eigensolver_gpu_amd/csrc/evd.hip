@@ -566,18 +566,39 @@ static int hegvdx_batch_workers(Ctx& c0, int nprob, int N, T* const* A, int lda,
     clear_phases(c0);
     const double t_all = now_ms();
     const int nworkers = c0.batch_workers < 0 ? auto_batch_workers() : c0.batch_workers;
-    const int several = nprob > 1 && nworkers > 1;
-    batch_run(c0.dev, nworkers, nprob, [&](int q) {
-        guarded(&infos[q], [&]() -> int {
+    // problems per launch chain that share the per-column launches of the tridiagonalization (lockstep groups, hegvdx_batch_core)
+    // Automatic: while a matrix is small (<= 96 MiB: complex N <= 2508, real N <= 3547) a solve is a chain of latency-bound
+    // launches and sharing them pays (C5, N = 2048: 83.8 -> 95-98 problems/s; complex N = 1024: 246 -> 361); above that the
+    // mat-vec streams and groups only take concurrency away (complex N = 3072: 34.6 -> 33.9).  profiles/r03_experiments.txt 15.
+    int fuse = c0.batch_fuse;
+    if (fuse < 1) {
+        const double mat_bytes = (double)sizeof(T) * N * (double)N;
+        fuse = (mat_bytes <= 96.0 * 1048576.0 && c0.tridiag_device) ? std::max(1, std::min(4, nprob / std::max(1, nworkers))) : 1;
+    }
+    if (fuse > 4) fuse = 4;   // (MAXB of the lockstep tridiagonalization)
+    if (!c0.tridiag_device) fuse = 1;   // (the lockstep core needs the device tridiagonal solver)
+    const int ngroups = (nprob + fuse - 1) / fuse;
+    const int several = ngroups > 1 && nworkers > 1;
+    batch_run(c0.dev, nworkers, ngroups, [&](int gi) {
+        const int q0 = gi * fuse, nq = std::min(fuse, nprob - q0);
+        for (int q = q0; q < q0 + nq; ++q) infos[q] = -2;   // (sentinel: a group cut short by an exception fails as a whole)
+        guarded(nullptr, [&]() -> int {
             Ctx& c = ctx();
             copy_options(c, c0);
             struct InBatch { Ctx& c; explicit InBatch(Ctx& c_, int v) : c(c_) { c.in_batch = v; } ~InBatch() { c.in_batch = 0; } } ib(c, several);
-            return hegvdx_core<T>(c, N, A[q], lda, B[q], ldb, Z[q], ldz, il, iu, w_d[q], e_d[q], tau_d[q], W_d[q], w_h[q], nullptr,
-                                  nullptr, N, nullptr, 0, nullptr, 0, Z_h ? Z_h[q] : nullptr, ldz_h, skip_host_copy, name);
+            if (nq == 1)
+                return infos[q0] = hegvdx_core<T>(c, N, A[q0], lda, B[q0], ldb, Z[q0], ldz, il, iu, w_d[q0], e_d[q0], tau_d[q0], W_d[q0],
+                                                  w_h[q0], nullptr, nullptr, N, nullptr, 0, nullptr, 0, Z_h ? Z_h[q0] : nullptr, ldz_h,
+                                                  skip_host_copy, name);
+            return hegvdx_batch_core<T>(c, nq, N, A + q0, lda, B + q0, ldb, Z + q0, ldz, il, iu, w_d + q0, e_d + q0, tau_d + q0, W_d + q0,
+                                        w_h + q0, Z_h ? Z_h + q0 : nullptr, ldz_h, skip_host_copy, infos + q0, name);
         });
     });
     int bad = 0;
-    for (int q = 0; q < nprob; ++q) bad |= (infos[q] != 0);
+    for (int q = 0; q < nprob; ++q) {
+        if (infos[q] == -2) infos[q] = -1;
+        bad |= (infos[q] != 0);
+    }
     c0.phase_ms[PH_TOTAL] = now_ms() - t_all;
     return bad ? -1 : 0;
 }

@@ -39,7 +39,7 @@ int eigsolve_set_lapack(const char *path);
 int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance","batch_workers"};
+ * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance","batch_workers","batch_fuse"};
  * value<=0 restores the default, except where 0 is itself a setting: "tridiag", "gst", "overlap" (value<0 restores the
  * default), "potrf" (0 = recursive form, anything else = block rows), "batch_workers" (0 = lockstep form, value<0 or >16 = automatic).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
  * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
@@ -55,6 +55,9 @@ int eigsolve_set_host_threads(int nthreads);
  * 64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
  * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default automatic: 4 when the process allows
  * >= 5 hardware queues through GPU_MAX_HW_QUEUES, else 3; 0 = lockstep form).
+ * "batch_fuse": problems per launch chain of a batch call that share the per-column launches of the tridiagonalization (lockstep
+ * groups, 1..4; default automatic: min(4, problems / chains) while a matrix is <= 96 MiB -- complex N <= 2508, real N <= 3547 --,
+ * else 1): C5 (64 x zhegvdx N=2048) 83.8 -> 98 problems/s, complex N = 1024 246 -> 361; bit-identical per-problem results.
  * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
  * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
  * larger than "gst_thr" (default 1024), two solves below.

@@ -1374,16 +1374,17 @@ def test_real_path_il_quirk_option(env):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("workers", [3, 0])
+@pytest.mark.parametrize("workers,fuse", [(3, -1), (0, -1), (3, 2), (2, 4)])
 @pytest.mark.parametrize("n,m,nprob", [(130, 40, 2), (300, 75, 3), (97, 97, 5), (1100, 200, 2)])
-def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, workers):
+def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, workers, fuse):
     """eigsolve_?hegvdx_batch / ?sygvdx_batch: nprob problems of one order in one call from one thread -- on the library's
-    worker threads (default, `batch_workers` problems in flight, each an ordinary single solve on its own context) or,
+    worker threads (default, `batch_workers` launch chains in flight, each an ordinary single solve on its own context), or,
     batch_workers = 0, on the caller's context with the tridiagonalizations in lockstep (every per-column launch carries
-    all problems; 5 problems: more than one lockstep group).  Eigenvalues, eigenvectors, the factor left in B and the
-    preserved strict lower triangle of A must be bit-identical to nprob calls of the single-problem driver."""
+    all problems; 5 problems: more than one lockstep group), or the mixture the library picks for small orders
+    (`batch_fuse` = g: every worker takes lockstep groups of g problems).  Eigenvalues, eigenvectors, the factor left in B
+    and the preserved strict lower triangle of A must be bit-identical to nprob calls of the single-problem driver."""
     torch, oracle, api = env
-    assert api.set_option("batch_workers", workers) == 0
+    assert api.set_option("batch_workers", workers) == 0 and api.set_option("batch_fuse", fuse) == 0
     probs = [(oracle.gen_spd_fast(n, 8800 + 31 * q + n, cplx), oracle.gen_spd_fast(n, 9900 + 37 * q + n, cplx, shift=float(n)))
              for q in range(nprob)]
 
@@ -1403,7 +1404,8 @@ def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, wor
     try:
         infos = api.hegvdx_batch(pairs, 1, m, wss)
     finally:
-        api.set_option("batch_workers", 3)
+        api.set_option("batch_workers", -1)
+        api.set_option("batch_fuse", -1)
     assert infos == [0] * nprob
     for q in range(nprob):
         w1, Z1, A1, B1 = single[q]
@@ -1416,13 +1418,15 @@ def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, wor
         assert oracle.residual(*probs[q], w, Z) <= n * EPS
 
 
-@pytest.mark.parametrize("workers", [3, 0])
-def test_batch_driver_error_reporting(env, workers):
+@pytest.mark.parametrize("workers,fuse", [(3, -1), (0, -1), (2, 2)])
+def test_batch_driver_error_reporting(env, workers, fuse):
     """One problem of the batch has a B that is not positive definite: info = -1 for that problem only, the others are
-    solved; a null entry in the pointer arrays is rejected with info = -1 for every problem (no dereference)."""
+    solved (also when it shares a lockstep group with a good one); a null entry in the pointer arrays is rejected with
+    info = -1 for every problem (no dereference)."""
     torch, oracle, api = env
     n, m = 150, 30
     api.set_option("batch_workers", workers)
+    api.set_option("batch_fuse", fuse)
     A = [oracle.gen_spd_fast(n, 500 + q, True) for q in range(3)]
     B = [oracle.gen_spd_fast(n, 600 + q, True, shift=float(n)) for q in range(3)]
     B[1][70, 70] = -3.0
@@ -1439,4 +1443,5 @@ def test_batch_driver_error_reporting(env, workers):
         assert api.hegvdx_batch(pairs, 1, m, wss, null_entry="w_h") == [-1, -1, -1]
         assert torch.equal(pairs[0][0], api.to_device(np.triu(A[0])))        # nothing was touched
     finally:
-        api.set_option("batch_workers", 3)
+        api.set_option("batch_workers", -1)
+        api.set_option("batch_fuse", -1)
