@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, help="host threads per GPU issuing solver calls (persistent, one library "
                     "context each); default 1: the concurrency lives inside the library (--workers)")
     ap.add_argument("--fuse", type=int, default=0, help="problems per solver call (eigsolve_?hegvdx_batch); 0 (default) = the whole "
-                    "batch of a step in one call (c5: 8 per call); 1 = the reference's one-problem-per-call driver")
+                    "batch of a step in one call (c5: 16 per call); 1 = the reference's one-problem-per-call driver")
     ap.add_argument("--workers", type=int, default=-1, help="library option batch_workers: problems in flight inside one batch call "
                     "(-1 = automatic: 4 when GPU_MAX_HW_QUEUES >= 5, else 3; 0 = lockstep tridiagonalizations on the caller's "
                     "context); measured at C3: 2 -> 14.7, 3 -> 16.0, 4 -> 16.3 (8 queues) / 14.1 (4 queues), 5 -> 12.4")

@@ -24,7 +24,7 @@ python $R/tools/trace_phases.py $(find /tmp/tr2 -name "*.db" | head -1) $O/r03_p
 cd $R; timeout 600 bash tools/pmc_collect.sh gpurun_out/r03_pmc $O/r03_pmc_summary.txt $O/r03_hemv_traffic.json
 # (5) un-traced bench lines: the default (C3), C2, C5 as the timed workload, C4
 python bench.py > $O/r03_bench_c3.json 2> $O/r03_bench_c3.err
-python bench.py --real --n 2048 --no-c5 > $O/r03_bench_c2_dsygvdx_n2048.json 2> $O/r03_bench_c2.err
+python bench.py --real --n 2048 --no-c5 --batch 16 > $O/r03_bench_c2_dsygvdx_n2048.json 2> $O/r03_bench_c2.err
 python bench.py --workload c5 --steps 3 --no-cpu-baseline --no-host-tridiag > $O/r03_bench_c5_1gpu.json 2> $O/r03_bench_c5.err
 python bench.py --n 8192 --m 8192 --batch 1 --steps 2 --warmup 1 --no-c5 --no-cpu-baseline --no-host-tridiag --same-problems > $O/r03_bench_c4_n8192_full.json 2> $O/r03_bench_c4.err
 ls -la $O
