@@ -37,7 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # Hardware queues.  Every launch chain of a batch wants a hardware queue of its own next to the null stream's; ROCm gives a
 # process 4 by default, which fits 3 problems in flight (16.1 problems/s at C3, 68 at C5).  Allowing more lets the library run 4
-# chains -- its automatic choice when GPU_MAX_HW_QUEUES >= 5: 16.4 at C3, 83 at C5 (the latency-bound small orders gain most;
+# chains -- its automatic choice when GPU_MAX_HW_QUEUES >= 5: 16.6 at C3, 84 at C5 -- 98 with lockstep groups -- (the latency-bound small orders gain most;
 # flat for 5 / 6 / 8 / 16).  This is the documented ROCm knob a batch integrator sets.  The result no
 # longer depends on stream creation order (round 2: a 2x swing at 8 queues) -- the library leases one stream per call.  An
 # explicit value in the environment wins.  Must happen before the HIP runtime starts (torch import).

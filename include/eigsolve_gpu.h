@@ -111,7 +111,7 @@ int eigsolve_dsygvdx(int N, double *A_d, int lda, double *B_d, int ldb, double *
 /* Batch of nprob problems of ONE order (QE k-point style, BASELINE.json configs[4]) solved by one call from one host thread.
  * The library keeps "batch_workers" (automatic: 3, or 4 with GPU_MAX_HW_QUEUES >= 5) of the problems in flight on its own
  * worker threads -- the caller's thread is one of them --, each problem an ordinary single-problem solve on a context and stream of its own, so that the
- * latency-bound phases of one solve fill under the kernels of the others (C3: 16.4 problems/s against 10.3 for one call
+ * latency-bound phases of one solve fill under the kernels of the others (C3: 16.6 problems/s against 10.3 for one call
  * per problem).  "batch_workers" = 0: everything on the caller's context, the tridiagonalizations in LOCKSTEP (every
  * per-column launch carries all problems), the other phases problem after problem.  Arguments as eigsolve_zhegvdx /
  * eigsolve_dsygvdx with one pointer per problem (host arrays of nprob device / host pointers, no null entries; Z_h may be
