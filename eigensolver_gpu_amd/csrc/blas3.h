@@ -91,6 +91,9 @@ template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* 
 template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb);
 // Rebuilds slot "invU" from an existing factor.
 template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
+// block-row factorizations of nprob <= 4 matrices in lockstep (one block-row launch per block row for all of them); no inverse
+// blocks are built; info of problem q in c.d_info[4 + q]
+template <class T> void potrf_upper_group(Ctx& c, hipStream_t st, int N, int nprob, T* const* B, int ldb);
 
 // Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)).
 template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X <- U^-1 X

@@ -977,11 +977,18 @@ __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, i
 // of the current factorization) that its copy sits in registers.  Nobody waits for workgroup 0, so the spin cannot deadlock.
 // (7 waves per SIMD = 72 VGPRs: the sixteen waves of a block-row workgroup then fit on a CU beside ONE 224-VGPR product workgroup
 // of the overlapped hegst chain instead of needing a completely empty CU -- potrf || hegst pipeline below)
+// up to four factorizations of one order side by side (blockIdx.y = problem: the lockstep groups of a batch call); every
+// problem has its own info word and its own announce counter
+constexpr int CHOL_MAXB = 4;
+template <class T> struct CholBatch { T* B[CHOL_MAXB]; };
 template <class T>
 __global__ void __launch_bounds__(DGT) __attribute__((amdgpu_waves_per_eu(7, 7)))
-chol_row_kernel(int n_total, T* Bm, int ldb, int k0, int* info, unsigned* loaded, unsigned expect) {
+chol_row_kernel(int n_total, CholBatch<T> cb, int ldb, int k0, int* info0, unsigned* loaded0, unsigned expect) {
     __shared__ T rowb[2][DB];   // pivot row of the diagonal block
     __shared__ T rowp[2][DB];   // pivot row of this workgroup's chunk
+    T* const Bm = cb.B[blockIdx.y];
+    int* const info = info0 + blockIdx.y;
+    unsigned* const loaded = loaded0 + blockIdx.y;
     const int tid = threadIdx.x;
     const int tr = tid / NTD, tc = tid % NTD;
     const int chunk = blockIdx.x;
@@ -1476,23 +1483,42 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 // broadcast, barrier): a 4x4-cyclic 256-thread layout, a scaled look-ahead broadcast and a blocked-by-16 elimination (rank-16
 // updates, 16x fewer barriers per multiply-add) all measured 40-44 us per launch like this one (profiles/r02_experiments.txt;
 // kernels in the git history of round 2).
-// block rows kb0 .. kb1-1 of the right-looking factorization (`expect`: the cumulative announce count of chol_row_kernel)
-template <class T> static void potrf_block_rows(Ctx& c, hipStream_t st, int N, T* B, int ldb, int kb0, int kb1, unsigned& expect) {
-    unsigned* loaded = reinterpret_cast<unsigned*>(c.d_info) + 2;   // its own word (d_info[1] is stedc's), zeroed by the caller
+// block rows kb0 .. kb1-1 of the right-looking factorization of nprob (<= 4) matrices of one order in lockstep: ONE block-row
+// launch per block row for all of them (blockIdx.y = problem), one rank-64 update per problem.  `expect`: the cumulative
+// announce count of chol_row_kernel; info0 / loaded0: nprob consecutive words each, zeroed by the caller.
+template <class T>
+static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const* B, int ldb, int kb0, int kb1, unsigned& expect,
+                             int* info0, unsigned* loaded0) {
+    CholBatch<T> cb;
+    for (int q = 0; q < CHOL_MAXB; ++q) cb.B[q] = B[q < nprob ? q : 0];
     for (int kb = kb0; kb < kb1; ++kb) {
         const int k0 = kb * DB;
         const int nb = min(DB, N - k0), rem = N - k0 - nb;
         const int chunks = (rem + DB - 1) / DB;
         expect += (unsigned)chunks;
-        hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks), dim3(DGT), 0, st, N, B, ldb, k0, c.d_info, loaded, expect);
+        hipLaunchKernelGGL((chol_row_kernel<T>), dim3(1 + chunks, nprob), dim3(DGT), 0, st, N, cb, ldb, k0, info0, loaded0, expect);
         if (rem > 0) {
-            const T* B12 = B + (size_t)k0 + (size_t)(k0 + nb) * ldb;
-            Epi e; e.uplo = 1; e.herm_diag = 1;
-            gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
-                    B + (size_t)(k0 + nb) + (size_t)(k0 + nb) * ldb, ldb, e);
+            for (int q = 0; q < nprob; ++q) {
+                const T* B12 = B[q] + (size_t)k0 + (size_t)(k0 + nb) * ldb;
+                Epi e; e.uplo = 1; e.herm_diag = 1;
+                gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
+                        B[q] + (size_t)(k0 + nb) + (size_t)(k0 + nb) * ldb, ldb, e);
+            }
         }
     }
     EIG_HIP(hipGetLastError());
+}
+template <class T> static void potrf_block_rows(Ctx& c, hipStream_t st, int N, T* B, int ldb, int kb0, int kb1, unsigned& expect) {
+    T* one[1] = {B};
+    potrf_block_rows<T>(c, st, N, 1, one, ldb, kb0, kb1, expect, c.d_info, reinterpret_cast<unsigned*>(c.d_info) + 2);
+}
+
+// The factorizations of a lockstep group (batch calls): block rows only -- the inverse diagonal blocks live in ONE set of scratch
+// slots per context and are built per problem by the caller right before they are used.  info of problem q: c.d_info[4 + q].
+template <class T> void potrf_upper_group(Ctx& c, hipStream_t st, int N, int nprob, T* const* B, int ldb) {
+    EIG_HIP(hipMemsetAsync(c.d_info, 0, 16 * sizeof(int), st));
+    unsigned expect = 0;
+    potrf_block_rows<T>(c, st, N, nprob, B, ldb, 0, (N + DB - 1) / DB, expect, c.d_info + 4, reinterpret_cast<unsigned*>(c.d_info) + 8);
 }
 
 // inverses of the 64x64 diagonal blocks blk0 .. blk0+nb-1 of a finished factor
@@ -1781,6 +1807,7 @@ template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, con
     template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \
     template void build_inv_blocks<T>(Ctx&, hipStream_t, int, const T*, int);                                            \
     template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \
+    template void potrf_upper_group<T>(Ctx&, hipStream_t, int, int, T* const*, int);                                     \
     template bool pipeline_applicable<T>(const Ctx&, int);                                                               \
     template void potrf_hegst_pipelined_begin<T>(Ctx&, int, T*, int, T*, int);                                           \
     template void hegst_pipelined_finish<T>(Ctx&, int, T*, int, const T*, int);

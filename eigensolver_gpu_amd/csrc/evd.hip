@@ -491,10 +491,26 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
     int* h_inf = reinterpret_cast<int*>(c.host_scratch_bytes("batch_info", sizeof(int) * (size_t)nprob));
     {
         PhaseRange r("batch: potrf + hegst");
-        for (int q = 0; q < nprob; ++q) {
-            potrf_upper<T>(c, st, N, B[q], ldb);
-            EIG_HIP(hipMemcpyAsync(&h_inf[q], c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-            hegst_upper<T>(c, st, N, A[q], lda, B[q], ldb);     // (meaningless if B[q] was not positive definite: checked below)
+        if (c.potrf_mode != 0 && nprob > 1) {
+            // the block-row chains of the group in lockstep (64 x 42 us of latency per factorization, shared), then per problem:
+            // its inverse diagonal blocks (one set of scratch slots per context) and its reduction to standard form
+            for (int q0 = 0; q0 < nprob; q0 += 4) {
+                const int nq = std::min(4, nprob - q0);
+                potrf_upper_group<T>(c, st, N, nq, B + q0, ldb);
+                for (int q = q0; q < q0 + nq; ++q)
+                    EIG_HIP(hipMemcpyAsync(&h_inf[q], c.d_info + 4 + (q - q0), sizeof(int), hipMemcpyDeviceToHost, st));
+                for (int q = q0; q < q0 + nq; ++q) {
+                    build_invU<T>(c, st, N, (const T*)B[q], ldb);
+                    build_inv_blocks<T>(c, st, N, (const T*)B[q], ldb);
+                    hegst_upper<T>(c, st, N, A[q], lda, B[q], ldb);   // (meaningless if B[q] was not positive definite: checked below)
+                }
+            }
+        } else {
+            for (int q = 0; q < nprob; ++q) {
+                potrf_upper<T>(c, st, N, B[q], ldb);
+                EIG_HIP(hipMemcpyAsync(&h_inf[q], c.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+                hegst_upper<T>(c, st, N, A[q], lda, B[q], ldb);     // (meaningless if B[q] was not positive definite: checked below)
+            }
         }
     }
     {
