@@ -708,7 +708,8 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
         }
         const int nm = (int)h_md.size();
         for (int q = 0; q < nm; ++q) h_mdp[q] = h_md[q];
-        if (getenv("EIGSOLVE_DC_TIMING")) printf("dc level %d: %d merges, wait %.3f ms, host scan %.3f ms\n", level, nm, tq1 - tq0, now_ms_dc() - tq1);
+        static const bool dc_timing = getenv("EIGSOLVE_DC_TIMING") != nullptr;   // diagnostic: where a level's host time goes
+        if (dc_timing) printf("dc level %d: %d merges, wait %.3f ms, host scan %.3f ms\n", level, nm, tq1 - tq0, now_ms_dc() - tq1);
         EIG_HIP(hipMemcpyAsync(d_pack, h_pack, pack_bytes, hipMemcpyHostToDevice, st));
         if (rot_total > 0) {
             hipLaunchKernelGGL(dc_rotate_kernel, dim3((nmax + 255) / 256, nm), dim3(256), 0, st, (const MergeDesc*)d_md, (const int*)d_rp,
