@@ -133,6 +133,17 @@ def main():
     ap.add_argument("--share-gpu", action="store_true", help="self-test: every rank uses GPU 0 (multi-rank logic on a 1-GPU box)")
     args = ap.parse_args()
 
+    # --gpus N means N GPUs: launched plainly (no WORLD_SIZE in the environment) with N > 1, re-execute under
+    # torch.distributed.run, one rank per GPU -- the same command line the driver uses for its scaling runs.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
@@ -141,6 +152,9 @@ def main():
                                            shard_problems)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d, or plainly and let bench.py "
+                         "start its ranks)" % (args.gpus, world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -154,6 +168,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=args.backend)
+    comm_ranks = dist.get_world_size() if world > 1 else 1     # ranks of the process group (backend nccl = RCCL)
     cplx = not args.real
     c5 = args.workload == "c5"
     n = args.n or (2048 if c5 else 4096)
@@ -309,12 +324,30 @@ def main():
         elapsed = max(rank_ms) / 1e3
 
     # ---- validity: residual of worker 0's last solve against its pristine inputs (outside the timed region) -------
+    # The checked problem's pristine (A,B) stay resident: rank 0 hands them to LAPACK below (cpu_baseline), so that the residual
+    # of the line is printed next to LAPACK's own on the SAME input and judged by SURVEY.md 8(c)'s rule max(N eps, 4 x LAPACK's).
     resid = berr = bortho = None
+    Ap = Bp = w_last = None
     if "p" in last:
         Ap, Bp = gen_pair(n, cplx, problem_seed(cfg_index, last["p"], 0 if args.same_problems else last["step"]), dev)
         wsl = workspace(0, n)
         resid, berr, bortho = check_solution(torch, Ap, Bp, wsl.Z, wsl.w[:m], m)
-        del Ap, Bp
+        w_last = wsl.w[:m].clone()
+        if rank != 0 or args.no_cpu_baseline or world > 1:
+            Ap = Bp = None
+    # strict gate (second family): one problem with B += N*I (cond(B) ~ 1e2), residual <= N*eps or the bench fails
+    strict = None
+    if rank == 0:
+        As, Bs = gen_pair(n, cplx, problem_seed(cfg_index, 0, 0) + 7, dev, shift_b=float(n))
+        A2, B2 = As.clone(), Bs.clone()
+        wss_ = workspace(0, n)
+        info_s, _ = api.hegvdx(A2, B2, 1, m, wss_)
+        rs_, bes_, bos_ = check_solution(torch, As, Bs, wss_.Z, wss_.w[:m], m)
+        strict = {"family": "B += N*I (well conditioned)", "info": info_s, "residual": rs_, "bound_N_eps": n * EPS,
+                  "b_orthonormality": bos_, "pass": bool(info_s == 0 and rs_ <= n * EPS)}
+        del As, Bs, A2, B2
+        if not strict["pass"]:
+            raise RuntimeError("bench.py validity gate failed: %s" % strict)
     # optional result gather over RCCL/xGMI (outside the timed region; north_star: gather only)
     gathered = gather_eigenvalues(results or {}, n_total, m)
     staged.clear()
@@ -347,6 +380,8 @@ def main():
             "value": n_total * K / elapsed,
             "unit": "problems/s",
             "n_gpus": world,
+            "rccl_ranks": comm_ranks if (world > 1 and args.backend == "nccl") else None,
+            "comm": {"backend": args.backend if world > 1 else None, "ranks": comm_ranks},
             "steps": K,
             "warmup": W,
             "ms_per_step": ms_step,
@@ -374,6 +409,11 @@ def main():
             "isolated_one_stream": one_stream,
             "residual": resid, "residual_bound_N_eps": n * EPS, "backward_error_max": berr,
             "b_orthonormality": bortho,
+            "residual_note": "residual / backward error / B-orthonormality of problem %s of the LAST timed step, as the batch left it; "
+                             "judged by max(N eps, 4 x LAPACK's own residual on the same (A,B)) -- see residual_check (filled by the "
+                             "cpu_baseline leg); strict_gate = a well-conditioned problem gated at N eps" % (last.get("p")),
+            "residual_check": None,
+            "strict_gate": strict,
             "eigenvalues_gathered": list(gathered.shape) if gathered is not None else None,
             "host_cores": cores,
             "tridiagonal_solver": "device divide&conquer (stedc.hip)" if tri else "host LAPACK dstedc (reference behaviour)",
@@ -537,8 +577,12 @@ def main():
     # ---- CPU baseline (rank 0 only, N=1 only): LAPACK on the host cores, SAME (A,B) as the first GPU problem --------
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         import scipy.linalg as sl
-        Ah_np = A0.T.cpu().numpy()
-        Bh_np = B0.T.cpu().numpy()
+        # the (A,B) LAPACK gets = the checked problem of the last timed step (falls back to the isolated solve's pair)
+        same_as_timed = Ap is not None
+        if not same_as_timed:
+            Ap, Bp = A0, B0
+        Ah_np = Ap.T.cpu().numpy()
+        Bh_np = Bp.T.cpu().numpy()
         # warm-up (thread pool, pages) on a leading block -- the reference's driver runs the CPU case once before timing
         # it (test_zhegvdx.F90:172); a full-size warm-up would double the bench's run time
         sl.eigh(Ah_np[:512, :512], Bh_np[:512, :512] + 512 * np.eye(512), subset_by_index=[0, 127], driver="gvx")
@@ -554,18 +598,26 @@ def main():
         except Exception:
             nth = cores
         pfx = "z" if cplx else "d"
-        wg = ws0.w[:m].cpu().numpy()
         # LAPACK's own numbers on this (A,B), same checker as the GPU's (always print both)
         Zl = torch.from_numpy(np.ascontiguousarray(Zc_np.T)).to(dev)          # (m, N) row-major == N x m column-major
-        rl, bel, bol = check_solution(torch, A0, B0, Zl, torch.from_numpy(wc).to(dev), m)
-        Ai, Bi = A0.clone(), B0.clone()
+        rl, bel, bol = check_solution(torch, Ap, Bp, Zl, torch.from_numpy(wc).to(dev), m)
+        Ai, Bi = Ap.clone(), Bp.clone()
         info, _ = api.hegvdx(Ai, Bi, 1, m, ws0)
-        rg, beg, bog = check_solution(torch, A0, B0, ws0.Z, ws0.w[:m], m)
+        rg, beg, bog = check_solution(torch, Ap, Bp, ws0.Z, ws0.w[:m], m)
+        wg = ws0.w[:m].cpu().numpy()
         del Zl, Ai, Bi
+        if same_as_timed:
+            bound = max(n * EPS, 4.0 * rl)
+            out["residual_check"] = {"residual_gpu_timed_solve": resid, "residual_lapack_same_problem": rl,
+                                     "bound_max_N_eps_4x_lapack": bound, "pass": bool(resid is not None and resid <= bound),
+                                     "b_orthonormality_gpu": bortho, "b_orthonormality_lapack": bol,
+                                     "eigenvalues_bit_identical_isolated_vs_batch": bool(torch.equal(ws0.w[:m], w_last))}
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "problems/s", "cores": nth, "kind": "port",
-                               "sample": "LAPACK %s (scipy %s / OpenBLAS) on the SAME (A,B) as the isolated GPU solve: N=%d eigenpairs "
+                               "sample": "LAPACK %s (scipy %s / OpenBLAS) on the SAME (A,B) as %s: N=%d eigenpairs "
                                          "1..%d, after a small warm-up call, one timed call; this is the routine the reference mirrors "
-                                         "(README.md:19-20)" % (pfx + ("hegvx" if cplx else "sygvx"), __import__("scipy").__version__, n, m),
+                                         "(README.md:19-20)" % (pfx + ("hegvx" if cplx else "sygvx"), __import__("scipy").__version__,
+                                                                "the checked problem of the last timed step" if same_as_timed else
+                                                                "the isolated GPU solve", n, m),
                                "ms": tc * 1e3,
                                "gvd": {"ms": td * 1e3, "value": 1.0 / td,
                                        "sample": "LAPACK %s (all N eigenpairs), what the reference's test driver times on the CPU "

@@ -21,7 +21,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libeigsolve_gpu.so")
+# EIGSOLVE_GPU_LIB: another build of the SAME library (A/B measurements of compile-time variants, tools/); never a fallback
+LIB_PATH = os.environ.get("EIGSOLVE_GPU_LIB") or os.path.join(_HERE, "lib", "libeigsolve_gpu.so")
 _lib = None
 
 c_int = ctypes.c_int
@@ -100,6 +101,12 @@ def _sync():
 def init_eigsolve_gpu():
     """eigsolve_vars.F90:39-59."""
     return lib().eigsolve_init()
+
+
+def finalize():
+    """eigsolve_finalize: releases the calling thread's context for the current device, the contexts of the library's
+    worker threads and of finished threads, and the idle streams of the pool.  The next call re-creates what it needs."""
+    return lib().eigsolve_finalize()
 
 
 # ---- module nvtx_inters ---------------------------------------------------------------------------

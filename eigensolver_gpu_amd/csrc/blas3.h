@@ -52,8 +52,8 @@ template <class T> Operand<T> opB(char t, const T* p, int ld) {
 struct Epi {
     int uplo = 0;       // 0 full, 1 write only i<=j, 2 write only i>=j
     int herm_diag = 0;  // force Im C(i,i) = 0
-    int inplace = 0;    // C aliases an operand: 1 = B operand (needs ONE tile along M, M <= 64),
-                        //                       2 = A operand (needs ONE tile along N, N <= 64)
+    void* aux = nullptr;  // != nullptr: alpha * A * B (the product before beta * C is added) is ALSO stored here (type T, ld ldaux)
+    int ldaux = 0;
 };
 
 // Strided batch descriptor: entry zb = 0..count-1 uses A.p + zb*sA, Bt.p + zb*sB, C + zb*sC, mask offsets + zb*dMoff*,
@@ -95,10 +95,12 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 // blocks are built; info of problem q in c.d_info[4 + q]
 template <class T> void potrf_upper_group(Ctx& c, hipStream_t st, int N, int nprob, T* const* B, int ldb);
 
-// Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)).
-template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X <- U^-1 X
-template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X <- U^-H X
-template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base = 64);  // X(mxn) <- X U^-1
+// Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)), OUT OF PLACE: the result goes to
+// Y, X is used as workspace and destroyed (its blocks receive the updates of the substitution).  No staging copies: the
+// base-case products read X and write Y, the updates read Y and modify X.  X and Y must not overlap.
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y = U^-1 X
+template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y = U^-H X
+template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y(mxn) = X U^-1
 // merged 256x256 inverse diagonal blocks for base = 256 (needs the 64-block inverses of potrf_upper / build_invU)
 template <class T> void build_inv256(Ctx& c, hipStream_t st, int N, const T* U, int ldu);
 // all merged inverse blocks the "trsm_base" option asks for (256, 512, 1024), from the 64-block inverses

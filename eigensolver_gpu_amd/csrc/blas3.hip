@@ -1,20 +1,20 @@
-// blas3.hip -- fp64 MFMA (v_mfma_f64_16x16x4_f64) tile engine for gfx950 and the blocked
-// routines built on it.  Replaces every cuBLAS/cuSOLVER BLAS-3 call site of the reference
-// (SURVEY.md 2.3): gemm, her2k/syr2k, herk/syrk, trmm, trsm, potrf, and the hegst blocking.
+// blas3.hip -- fp64 MFMA tile engine for gfx950 and the blocked routines built on it.  Replaces every cuBLAS/cuSOLVER
+// BLAS-3 call site of the reference: gemm, her2k/syr2k, herk/syrk, trmm, trsm, potrf, and the hegst blocking.
 //
 // Design (CDNA4-first, not a translation of any vendor kernel):
-//  * one kernel template  gemm_kernel<T, BM, BN, TA, TB>  with 4 wave64 waves in a 2x2 grid;
-//    operands are staged global -> registers -> LDS with the next K-slab's global loads in
-//    flight during the MFMA phase (register prefetch), complex data split into re/im planes
-//    in LDS so every MFMA operand is one conflict-free ds_read_b64;
-//  * LDS layouts are chosen per operand from how it sits in HBM ("idx-contiguous" or
-//    "k-contiguous") so global reads are always coalesced and LDS reads bank-conflict-free
-//    (row padding 16 doubles / 2 doubles, see MI355X_MICROARCH.md LDS table);
-//  * the MFMA is issued as D[n][m] (B fragment first) so that the 16 lanes of a fragment
-//    row own 16 consecutive rows of C -> 128/256-byte contiguous C read-modify-write;
-//  * triangular / unit-trapezoid masks, conjugation, K-concatenation (her2k in one pass over
-//    C) and triangular-output filtering are folded into the operand loader / epilogue, so no
-//    operand is ever physically modified (the reference stashes/zeros/restores blocks of A).
+//  * ONE kernel template  gemm_fast_kernel<T, BM, BN, TA, TB, BK, MASKED>  with 4 wave64 waves in a 2x2 grid; operands are
+//    staged global -> registers -> LDS (double-buffered, one barrier per K-slab, the loads of slab k+2 in flight during the
+//    MFMAs of slab k), complex data split into re/im planes in LDS so every MFMA operand is one conflict-free ds_read_b64;
+//  * LDS layouts are chosen per operand from how it sits in HBM ("idx-contiguous" or "k-contiguous") so global reads are
+//    always coalesced and LDS reads bank-conflict-free: idx-contiguous slabs are XOR-swizzled (no padding), k-contiguous
+//    rows padded by 2 doubles (MI355X_MICROARCH.md LDS table);
+//  * the MFMA is issued as D[n][m] (B fragment first) so that the 16 lanes of a fragment row own 16 consecutive rows of C
+//    -> 128/256-byte contiguous C read-modify-write;
+//  * triangular / unit-trapezoid masks, conjugation, K-concatenation (her2k in one pass over C) and triangular-output
+//    filtering are folded into the operand loader / epilogue, so no operand is ever physically modified (the reference
+//    stashes/zeros/restores blocks of A);
+//  * workgroup -> tile mapping is XCD-aware (tile_of): the workgroups that are resident on one XCD at a time cover a compact
+//    super-tile of C, so the operand panels they share are fetched into that XCD's L2 once.
 #include <type_traits>
 
 #include "blas3.h"
@@ -23,6 +23,14 @@
 namespace eig {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+// workgroup -> tile maps (GemmArgs::map)
+enum TileMapKind {
+    TM_GRID = 0,      // tile = (blockIdx.x, blockIdx.y)
+    TM_RECT = 1,      // 1-D grid over 64-slot super-tiles of a tile rectangle, dealt XCD by XCD (see tile_of)
+    TM_FOLD = 2,      // the same over the stored triangle of a square tile grid folded into a rectangle
+    TM_TRI = 3,       // 1-D grid over the tiles of the stored triangle, plain enumeration (small / batched grids)
+};
 
 template <class T> struct GemmArgs {
     int M, N, K;
@@ -34,44 +42,56 @@ template <class T> struct GemmArgs {
     int kchunk;      // >0: split-K, blockIdx.z owns [z*kchunk, (z+1)*kchunk)
     T* P;            // split-K partial output (M x N per split, ld = M)
     size_t pstride;
-    int tri;         // 1: 1-D grid over the tiles of the stored triangle only (see tile_of)
-    GemmBatch bt;    // count > 0: blockIdx.z = batch entry * bt.splits + K-split (gemm_fast_kernel only)
+    int map;         // TileMapKind
+    int mw, mh;      // TM_RECT / TM_FOLD: the tile rectangle
+    int msw, msh;    // log2 of the super-tile's width / height (msw + msh = 6)
+    int mnsx;        // super-tiles along x
+    int mfull;       // slots below this index are dealt in XCD chunks, the rest round-robin
+    int mnt;         // TM_FOLD: (even) order of the tile triangle
+    GemmBatch bt;    // count > 0: blockIdx.z = batch entry * bt.splits + K-split
 };
 
-// Tile owned by this workgroup.  Triangular outputs (epi.uplo) on a square tile grid are launched as a 1-D grid
-// over the ACTIVE tiles only: with a 2-D grid and an early exit the hardware's round-robin of workgroup ids over
-// the 8 XCDs leaves them unevenly loaded (order-1984 upper update: 496 tiles <= 512 resident slots, yet one XCD
-// receives 76 tiles for its 64 slots and the launch takes two rounds; measured 27 -> 4x TFLOP/s).
-template <class T> __device__ __forceinline__ void tile_of(const GemmArgs<T>& g, int& bx, int& by) {
-    if (!g.tri) { bx = blockIdx.x; by = blockIdx.y; return; }
-    const int t = blockIdx.x;
-    int q = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((q + 1) * (q + 2) / 2 <= t) ++q;
-    while (q * (q + 1) / 2 > t) --q;
-    const int r = t - q * (q + 1) / 2;   // r <= q
-    if (g.epi.uplo == 1) { bx = r; by = q; } else { bx = q; by = r; }
-}
-
-template <class T>
-__device__ __forceinline__ T fetch(const Operand<T>& o, int idx, int k, int nidx, int kend) {
-    // branch-free: always load from a clamped valid address, then select
-    bool keep = idx < nidx && k < kend, one = false;
-    const bool seg2 = k >= o.k1;
-    const T* p = seg2 ? o.p2 : o.p;
-    const int ld = seg2 ? o.ld2 : o.ld;
-    const int kk = seg2 ? k - o.k1 : k;
-    const int sr = o.trans ? kk : idx;
-    const int sc = o.trans ? idx : kk;
-    if (o.mask != M_NONE) {
-        const int d = sr - sc - o.moff;
-        const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
-        one = keep && (o.mask == M_UNITTRAP) && (d == 0);
-        keep = keep && km;
+// Tile owned by this workgroup; false = a padding slot of the map (nothing to do).
+//
+// Hardware facts used (MI355X_MICROARCH.md, "Workgroup dispatch"; for SPEED only, any placement gives the same results):
+// workgroup b of a launch runs on XCD b % 8, every XCD has a private 4 MB L2, and an XCD holds 64 of these workgroups at a
+// time (32 CUs x 2).  With tile = (blockIdx.x, blockIdx.y) the 64 workgroups an XCD works on are every 8th tile of a tile
+// column: they share ONE operand panel and read 64 different panels of the other operand -- zgemm 4096^3 fetched 8.3x its
+// algorithmic bytes from HBM / Infinity Cache (profiles/r03_pmc_summary.txt).  Here the tile grid is cut into super-tiles of
+// 64 tiles (8x8 unless the grid is narrow), and slot u of the 1-D launch maps to
+//     super-tile  (u / 512) * 8 + u % 8,   position (u % 512) / 8 inside it,
+// i.e. the k-th group of 64 workgroups that lands on XCD x is exactly one super-tile: 8 + 8 operand panels for 64 tiles.
+// The last, partial round of super-tiles (slots >= mfull) is dealt tile by tile so that all XCDs finish together.
+//
+// Triangular outputs (epi.uplo) on a square tile grid: only the nt(nt+1)/2 tiles of the stored triangle are launched (a
+// 2-D grid with an early exit left the XCDs unevenly loaded: 27 -> 4x TFLOP/s on an order-1984 update, round 2).  For the
+// super-tile map the triangle is FOLDED into the dense rectangle (nt/2) x (nt+1) (nt even; odd orders are padded by one):
+//     (i, j), j >  i  ->  tile (i, j - 1)                      rows 0 .. nt/2-1 of the triangle,
+//     (i, j), j <= i  ->  tile (nt-1-i, nt-1-j)                rows nt/2 .. nt-1, point-reflected,
+// both pieces of a super-tile are compact blocks of C.
+template <class T> __device__ __forceinline__ bool tile_of(const GemmArgs<T>& g, int& bx, int& by) {
+    if (g.map == TM_GRID) { bx = blockIdx.x; by = blockIdx.y; return true; }
+    int r, q;
+    if (g.map == TM_TRI) {
+        const int t = blockIdx.x;
+        q = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((q + 1) * (q + 2) / 2 <= t) ++q;
+        while (q * (q + 1) / 2 > t) --q;
+        r = t - q * (q + 1) / 2;   // r <= q
+    } else {
+        const unsigned u = blockIdx.x;
+        unsigned p = u;
+        if (u < (unsigned)g.mfull) p = ((((u >> 9) << 3) + (u & 7u)) << 6) + ((u & 511u) >> 3);
+        const unsigned s = p >> 6, j = p & 63u;
+        const unsigned sy = s / (unsigned)g.mnsx, sx = s - sy * (unsigned)g.mnsx;
+        const int i = (int)((sx << g.msw) + (j & ((1u << g.msw) - 1u)));
+        const int jj = (int)((sy << g.msh) + (j >> g.msw));
+        if (i >= g.mw || jj >= g.mh) return false;
+        if (g.map == TM_RECT) { bx = i; by = jj; return true; }
+        if (jj > i) { r = i; q = jj - 1; } else { r = g.mnt - 1 - i; q = g.mnt - 1 - jj; }
     }
-    const T* addr = keep ? p + (size_t)sr + (size_t)sc * ld : o.p;
-    T v = *addr;
-    if (o.conj) v = conj_(v);
-    return keep ? v : (one ? Tr<T>::one() : Tr<T>::zero());
+    if (g.epi.uplo == 1) { bx = r; by = q; } else { bx = q; by = r; }
+    return true;
 }
 
 // Restrict [kbeg,kend) to where a masked operand tile can be non-zero (skips the zero half of
@@ -89,221 +109,42 @@ __device__ __forceinline__ void trim_k(const Operand<T>& o, int i0, int bsz, int
     }
 }
 
-constexpr int BKL = 16;  // K-slab of the large tiles (register-prefetch pipelined)
-constexpr int BKS = 32;  // K-slab of the small tiles: K <= 64 (trsm/larfb/panel-sized products) is ONE stage
-
-#ifndef EIG_MFMA444
-#define EIG_MFMA444 1
-#endif
-
-template <class T, int BM, int BN, int TA, int TB, int BK>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs<T> g) {
-    constexpr bool CX = Tr<T>::cx;
-    constexpr int NPL = CX ? 2 : 1;
-    constexpr int LDA = TA == 0 ? BM + 16 : BK + 2;
-    constexpr int LDB = TB == 0 ? BN + 16 : BK + 2;
-    constexpr int ASZ = TA == 0 ? BK * LDA : BM * LDA;
-    constexpr int BSZ = TB == 0 ? BK * LDB : BN * LDB;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
-    __shared__ double sm[NPL * (ASZ + BSZ)];
-    double* As = sm;
-    double* Bs = sm + NPL * ASZ;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tbx, tby;
-    tile_of(g, tbx, tby);
-    const int i0 = tbx * BM, j0 = tby * BN;
-    if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
-    if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
-
-    int kbeg = 0, kend = g.K;
-    if (g.kchunk > 0) {
-        kbeg = blockIdx.z * g.kchunk;
-        kend = min(g.K, kbeg + g.kchunk);
-    }
-    trim_k(g.A, i0, BM, kbeg, kend);
-    trim_k(g.B, j0, BN, kbeg, kend);
-    kbeg &= ~(BK - 1);
-
-    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
-    d4 acc[NPL][TM][TN];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
-
-    T ra[EA], rb[EB];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int idx, k;
-            if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
-            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-            ra[e] = fetch(g.A, i0 + idx, k0 + k, g.M, kend);
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int idx, k;
-            if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
-            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-            rb[e] = fetch(g.B, j0 + idx, k0 + k, g.N, kend);
-        }
-    };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int e = 0; e < EA; ++e) {
-            int idx, k;
-            if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
-            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-            int off = TA == 0 ? k * LDA + idx : idx * LDA + k;
-            As[off] = real_(ra[e]);
-            if (CX) As[ASZ + off] = imag_(ra[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < EB; ++e) {
-            int idx, k;
-            if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
-            else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
-            int off = TB == 0 ? k * LDB + idx : idx * LDB + k;
-            Bs[off] = real_(rb[e]);
-            if (CX) Bs[BSZ + off] = imag_(rb[e]);
-        }
-    };
-
-    const int fi = lane & 15, fk = lane >> 4;
-    if (kbeg < kend) gload(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (k0 + BK < kend) gload(k0 + BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-#if EIG_MFMA444
-            // v_mfma_f64_4x4x4_4b_f64 sustains ~72 TFLOP/s on gfx950 where 16x16x4 saturates at ~48
-            // (profiles/r01_microbench3_mfma_variants.txt).  Four of them, fed with the 4-row slices
-            // r = 0..3 of the B fragment (replicated over lane bits 2-3) against the unchanged 16-wide
-            // A fragment, produce exactly one 16x16x4 product; result r lands in component r of the
-            // accumulator: lane l holds C(m = l&15, n = 4r + (l>>4))
-            // (layout measured in profiles/r01_probe_mfma_f64_4x4x4_layout.txt).  blgp bit 0 negates.
-            double ar[TM], ai[TM], br[TN][4], bi[TN][4];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                int m = wm0 + a * 16 + fi, k = kk + fk;
-                int off = TA == 0 ? k * LDA + m : m * LDA + k;
-                ar[a] = As[off];
-                if (CX) ai[a] = As[ASZ + off];
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    int n = wn0 + b * 16 + 4 * r + (lane & 3), k = kk + fk;
-                    int off = TB == 0 ? k * LDB + n : n * LDB + k;
-                    br[b][r] = Bs[off];
-                    if (CX) bi[b][r] = Bs[BSZ + off];
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ar[a], acc[0][a][b][r], 0, 0, 0);
-                        if (CX) {
-                            acc[0][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ai[a], acc[0][a][b][r], 0, 0, 1);
-                            acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[b][r], ar[a], acc[NPL - 1][a][b][r], 0, 0, 0);
-                            acc[NPL - 1][a][b][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[b][r], ai[a], acc[NPL - 1][a][b][r], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-#else
-            double ar[TM], ai[TM], br[TN], bi[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                int m = wm0 + a * 16 + fi, k = kk + fk;
-                int off = TA == 0 ? k * LDA + m : m * LDA + k;
-                ar[a] = As[off];
-                if (CX) ai[a] = As[ASZ + off];
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                int n = wn0 + b * 16 + fi, k = kk + fk;
-                int off = TB == 0 ? k * LDB + n : n * LDB + k;
-                br[b] = Bs[off];
-                if (CX) bi[b] = Bs[BSZ + off];
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    // D[n][m]: B fragment is the MFMA "A" operand -> lanes&15 of the result run along m.
-                    acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ar[a], acc[0][a][b], 0, 0, 0);
-                    if (CX) {
-                        acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], -ai[a], acc[0][a][b], 0, 0, 0);
-                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ar[a], acc[NPL - 1][a][b], 0, 0, 0);
-                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ai[a], acc[NPL - 1][a][b], 0, 0, 0);
-                    }
-                }
-            }
-#endif
-        }
-    }
-
-    // epilogue: lane owns (m = .. + (lane&15), n = .. + (lane>>4) + 4r)
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int gi = i0 + wm0 + a * 16 + fi;
-                int gj = j0 + wn0 + b * 16 + fk + 4 * r;
-                if (gi >= g.M || gj >= g.N) continue;
-                if (g.epi.uplo == 1 && gi > gj) continue;
-                if (g.epi.uplo == 2 && gi < gj) continue;
-                T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
-                if (g.kchunk > 0) {
-                    g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * g.M] = v;
-                } else {
-                    T* cp = g.C + (size_t)gi + (size_t)gj * g.ldc;
-                    T out = g.alpha * v;
-                    if (!(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0)) out = out + g.beta * (*cp);
-                    if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
-                    *cp = out;
-                }
-            }
-        }
-    }
-}
+constexpr int BKL = 16;  // K-slab of the 64x64 tiles
+constexpr int BKS = 32;  // K-slab of the 32x32 tiles: K <= 64 (panel-sized products) is two stages
 
 // ------------------------------------------------------------------------------------------------
-// gemm_fast_kernel: same math and LDS layouts as gemm_kernel, restructured for throughput:
+// gemm_fast_kernel
 //  * per-thread element descriptors (stored coordinates, validity, LDS offset) are computed ONCE; a stage's global
 //    loads are raw (clamped address only) and the mask / conjugation / zero-fill are applied one slab later, when
 //    the registers are written to LDS -- so the loads really stay in flight across the MFMAs of a slab;
-//  * K-concatenated operands (her2k) run as two phases over (p, ld) then (p2, ld2) -- the host
-//    guarantees k1 % BK == 0, otherwise the generic kernel is used;
+//  * K-concatenated operands (her2k) run as two segments over (p, ld) then (p2, ld2), each padded to whole slabs (the
+//    segment boundary k1 may be anything: remainder panels of the tridiagonalization);
 //  * LDS is double-buffered: the store of slab k+1 and the global loads of slab k+2 are issued
 //    before the MFMAs of slab k, ONE barrier per stage.
+//  * LDS per workgroup: idx-contiguous slabs carry no padding (XOR swizzle, below), so every instantiation stays below
+//    80 KB and TWO workgroups share a CU (the padded layout of round 3 put the complex 32x32 forms at 84-98 KB:
+//    one workgroup per CU, MFMA pipe 19-56 % busy on the solve's small products).
 // ------------------------------------------------------------------------------------------------
 template <class T, int BM, int BN, int TA, int TB, int BK, bool MASKED>
 __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     constexpr bool CX = Tr<T>::cx;
     constexpr int NPL = CX ? 2 : 1;
-    constexpr int LDA = TA == 0 ? BM + 16 : BK + 2;
-    constexpr int LDB = TB == 0 ? BN + 16 : BK + 2;
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && BK % 4 == 0, "tile shape");
+    // idx-contiguous operand: slab row k holds the BM (BN) entries of that k, entry idx at position idx ^ (16 * (k & 1)).
+    // A 16x4 fragment read (16 consecutive idx for 4 consecutive k; ds_read_b64 serves lanes 0-31 = two k's at once, 64
+    // banks of 4 B = 32 doubles) then finds its even-k half and its odd-k half in different halves of the banks.
+    // k-contiguous operand: row idx holds BK consecutive k, rows padded by 2 doubles (16 rows x 2 k's: distinct banks).
+    constexpr int LDA = TA == 0 ? BM : BK + 2;
+    constexpr int LDB = TB == 0 ? BN : BK + 2;
     constexpr int ASZ = TA == 0 ? BK * LDA : BM * LDA;
     constexpr int BSZ = TB == 0 ? BK * LDB : BN * LDB;
     constexpr int STG = NPL * (ASZ + BSZ);   // doubles per LDS stage
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     constexpr int EA = BM * BK / 256, EB = BN * BK / 256;
+    static_assert(2 * STG * sizeof(double) <= 80 * 1024, "two workgroups per CU");
     __shared__ double sm[2 * STG];
+    auto aoff = [](int idx, int k) -> int { return TA == 0 ? k * LDA + (idx ^ ((k & 1) << 4)) : idx * LDA + k; };
+    auto boff = [](int idx, int k) -> int { return TB == 0 ? k * LDB + (idx ^ ((k & 1) << 4)) : idx * LDB + k; };
 
     // (wave index made wave-uniform for the compiler: the wave's tile origin and LDS offsets then live in SGPRs, 2-5 VGPRs less)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -322,11 +163,11 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
         g.N = min(g.N, g.bt.capN - zb * g.bt.dcap);
     }
     int tbx, tby;
-    tile_of(g, tbx, tby);
+    if (!tile_of(g, tbx, tby)) return;
     const int i0 = tbx * BM, j0 = tby * BN;
     if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
     if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
-    if (i0 >= g.M || j0 >= g.N) return;      // (clipped batch entries)
+    if (i0 >= g.M || j0 >= g.N) return;      // (clipped batch entries, the padding row / column of an odd folded triangle)
 
     int kbeg = 0, kend = g.K;
     if (g.kchunk > 0) {
@@ -335,7 +176,15 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     }
     trim_k(g.A, i0, BM, kbeg, kend);
     trim_k(g.B, j0, BN, kbeg, kend);
-    kbeg &= ~(BK - 1);
+    // the K range as (up to) two segments, each walked in slabs of BK from its own start:
+    //   segment 1 = logical [kbeg, min(kend, k1)) on (p, ld), segment 2 = logical [max(kbeg, k1), kend) on (p2, ld2) at k - k1
+    const bool cat = g.A.k1 != INT_MAX;       // host guarantees A.k1 == B.k1
+    const int k1 = cat ? g.A.k1 : INT_MAX;
+    const int a1 = kbeg, b1 = min(kend, k1);
+    const int a2 = cat ? max(kbeg, k1) - k1 : 0, b2 = cat ? kend - k1 : 0;
+    const int nst1 = b1 > a1 ? (b1 - a1 + BK - 1) / BK : 0;
+    const int nst2 = b2 > a2 ? (b2 - a2 + BK - 1) / BK : 0;
+    const int nst = nst1 + nst2;
 
     const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
     d4 acc[NPL][TM][TN];
@@ -349,9 +198,8 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     // ---- element descriptors -----------------------------------------------------------------------
     // Per thread and element: global idx, k offset inside a slab, validity, LDS offset.  A slab's global loads are RAW
     // (clamped address, nothing else); mask / conjugation / zero-fill are applied when the registers go to LDS, one
-    // slab later.  (With the select next to the load -- the first form of this kernel -- hipcc waits for the loads right
-    // where they are issued: s_waitcnt vmcnt(0) in front of the MFMAs of EVERY slab, i.e. one exposed memory round trip
-    // per slab; found in the ISA in round 3.)
+    // slab later.  (With the select next to the load hipcc waits for the loads right where they are issued:
+    // s_waitcnt vmcnt(0) in front of the MFMAs of EVERY slab, i.e. one exposed memory round trip per slab; round 3.)
     int sia[EA], kla[EA], sib[EB], klb[EB];
     bool oka[EA], okb[EB];
     int offa[EA], offb[EB];   // LDS offsets inside a stage
@@ -361,7 +209,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
         if (TA == 0) { idx = tid % BM; k = tid / BM + e * (256 / BM); }
         else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
         sia[e] = i0 + idx; kla[e] = k; oka[e] = (i0 + idx) < g.M;
-        offa[e] = TA == 0 ? k * LDA + idx : idx * LDA + k;
+        offa[e] = aoff(idx, k);
     }
 #pragma unroll
     for (int e = 0; e < EB; ++e) {
@@ -369,11 +217,8 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
         if (TB == 0) { idx = tid % BN; k = tid / BN + e * (256 / BN); }
         else { k = tid % BK; idx = tid / BK + e * (256 / BK); }
         sib[e] = j0 + idx; klb[e] = k; okb[e] = (j0 + idx) < g.N;
-        offb[e] = NPL * ASZ + (TB == 0 ? k * LDB + idx : idx * LDB + k);
+        offb[e] = NPL * ASZ + boff(idx, k);
     }
-    // second segment (K-concatenation): same descriptors on (p2, ld2), logical k >= k1
-    const bool cat = g.A.k1 != INT_MAX;
-    const int k1 = cat ? g.A.k1 : kend;   // host guarantees A.k1 == B.k1 and k1 % BK == 0
 
     // keep / unit-diagonal predicates of one element (kk = k inside its segment, ke = end of the segment).  `need` is
     // wave-uniform: false when the mask cannot touch any element of the current (tile, slab) -- the mask arithmetic is
@@ -407,13 +252,13 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     T ra[EA], rb[EB];
     int pkl = 0, pke = 0;     // segment-local slab origin and segment end of the slab held in ra / rb
     bool pna = false, pnb = false;   // mask_active of that slab
-    auto gload = [&](int k0) {
-        const bool s2 = k0 >= k1;     // (never true without K-concatenation: k1 = kend)
+    auto gload = [&](int s_) {     // slab index 0 .. nst-1
+        const bool s2 = s_ >= nst1;
         const T* pa = s2 ? g.A.p2 : g.A.p;
         const T* pb = s2 ? g.B.p2 : g.B.p;
         const long la = s2 ? g.A.ld2 : g.A.ld, lb = s2 ? g.B.ld2 : g.B.ld;
-        pkl = s2 ? k0 - k1 : k0;
-        pke = s2 ? kend - k1 : min(kend, k1);
+        pkl = s2 ? a2 + (s_ - nst1) * BK : a1 + s_ * BK;
+        pke = s2 ? b2 : b1;
         pna = mask_active(g.A, TA, i0, BM, pkl);
         pnb = mask_active(g.B, TB, j0, BN, pkl);
 #pragma unroll
@@ -457,11 +302,10 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     };
 
     const int fi = lane & 15, fk = lane >> 4;
-    const int nst = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     if (nst > 0) {
-        gload(kbeg);
+        gload(0);
         lstore(sm);
-        if (nst > 1) gload(kbeg + BK);
+        if (nst > 1) gload(1);
         __syncthreads();
     }
     // C of the tile (beta != 0): requested BEFORE the MFMAs of the last slab -- the operand staging registers are dead by then --
@@ -483,15 +327,19 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
                     cv[a][b][r] = *cp;
                 }
     };
-    // the MFMAs of one K-slab (As / Bs: the LDS stage holding it)
+    // the MFMAs of one K-slab (As / Bs: the LDS stage holding it).
+    // v_mfma_f64_4x4x4_4b_f64 sustains ~72 TFLOP/s on gfx950 where 16x16x4 saturates at ~48
+    // (profiles/r01_microbench3_mfma_variants.txt).  Four of them, fed with the 4-row slices r = 0..3 of the B fragment
+    // (replicated over lane bits 2-3) against the unchanged 16-wide A fragment, produce exactly one 16x16x4 product; result r
+    // lands in component r of the accumulator: lane l holds C(m = l&15, n = 4r + (l>>4))
+    // (layout measured in profiles/r01_probe_mfma_f64_4x4x4_layout.txt).  blgp bit 0 negates.
     auto mma_slab = [&](const double* As, const double* Bs) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double ar[TM], ai[TM], br[TN][4], bi[TN][4];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                int m = wm0 + a * 16 + fi, k = kk + fk;
-                int off = TA == 0 ? k * LDA + m : m * LDA + k;
+                const int off = aoff(wm0 + a * 16 + fi, kk + fk);
                 ar[a] = As[off];
                 if (CX) ai[a] = As[ASZ + off];
             }
@@ -499,8 +347,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
             for (int b = 0; b < TN; ++b) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int n = wn0 + b * 16 + 4 * r + (lane & 3), k = kk + fk;
-                    int off = TB == 0 ? k * LDB + n : n * LDB + k;
+                    const int off = boff(wn0 + b * 16 + 4 * r + (lane & 3), kk + fk);
                     br[b][r] = Bs[off];
                     if (CX) bi[b][r] = Bs[BSZ + off];
                 }
@@ -535,7 +382,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     for (int s_ = 0; s_ + 1 < nst; ++s_) {
         const double* As = sm + (s_ & 1) * STG;
         lstore(sm + ((s_ + 1) & 1) * STG);                 // slab s+1 (registers) -> other buffer
-        if (s_ + 2 < nst) gload(kbeg + (s_ + 2) * BK);     // slab s+2 in flight during the MFMAs
+        if (s_ + 2 < nst) gload(s_ + 2);                   // slab s+2 in flight during the MFMAs
         mma_slab(As, As + NPL * ASZ);
         __syncthreads();
     }
@@ -549,6 +396,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     // epilogue, branch-free on the load side: all C reads of the tile were issued together (clamped addresses, load_c above),
     // here they are combined and stored under a predicate.  (`if (valid) { load; store; }` per element serialises 16
     // dependent round trips -- the same hipcc pattern as in the operand loads.)
+    T* const aux = reinterpret_cast<T*>(g.epi.aux);
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -565,6 +413,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
                     if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * pld] = v;
                 } else {
                     T out = g.alpha * v;
+                    if (aux && ok) aux[(size_t)gi + (size_t)gj * g.epi.ldaux] = out;
                     if (use_c) out = out + g.beta * cv[a][b][r];
                     if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
                     if (ok) g.C[(size_t)gi + (size_t)gj * g.ldc] = out;
@@ -592,53 +441,66 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
     for (int z = 0; z < splits; ++z) s = s + P[(size_t)z * pstride + id];
     T* cp = C + (size_t)i + (size_t)j * ldc;
     T out = alpha * s;
+    if (epi.aux) reinterpret_cast<T*>(epi.aux)[(size_t)i + (size_t)j * epi.ldaux] = out;
     if (!(real_(beta) == 0.0 && imag_(beta) == 0.0)) out = out + beta * (*cp);
     if (epi.herm_diag && i == j) out = Tr<T>::realpart(out);
     *cp = out;
 }
 
-static bool g_use_fast = getenv("EIGSOLVE_GEMM_GENERIC") == nullptr;
-
 // Split-K partial sums live in a per-stream scratch slot: with the two-stream overlap options gemms on c.s1 and c.s2
 // may both take the split path at the same time.
 static const char* splitk_slot(const Ctx& c, hipStream_t st) { return (c.s2 && st == c.s2) ? "splitk_s2" : "splitk"; }
 
+// Host side of tile_of: the map for a tm x tn tile grid (tri: only the stored triangle of a square grid is launched).
+// Super-tile shapes of 64 tiles; the one that pads the grid least wins, squarer shapes preferred (2 % per factor of two
+// of aspect ratio); grids of fewer than 128 tiles, batched launches and grids that would be padded by more than 15 %
+// keep the plain enumerations.
+template <class T> static dim3 choose_map(GemmArgs<T>& g, int tm, int tn, bool tri, int zdim, bool use_map) {
+    g.map = tri ? TM_TRI : TM_GRID;
+    g.mw = g.mh = g.msw = g.msh = g.mnsx = g.mfull = g.mnt = 0;
+    const long active = tri ? (long)tm * (tm + 1) / 2 : (long)tm * tn;
+    dim3 plain = tri ? dim3((unsigned)active, 1, zdim) : dim3(tm, tn, zdim);
+    if (!use_map || g.bt.count > 0 || active < 128) return plain;   // (option "tile_map" = 0: A/B measurements of the map)
+    int W = tm, H = tn, nte = 0;
+    if (tri) { nte = tm + (tm & 1); W = nte / 2; H = nte + 1; }
+    double bestc = 0.0;
+    int bw = -1;
+    long bpad = 0;
+    for (int lw = 0; lw <= 6; ++lw) {
+        const int lh = 6 - lw;
+        const long nsx = (W + (1 << lw) - 1) >> lw, nsy = (H + (1 << lh) - 1) >> lh;
+        const long pad = nsx * nsy * 64;
+        const double cost = (double)pad * (1.0 + 0.02 * abs(lw - lh));
+        if (bw < 0 || cost < bestc) { bestc = cost; bw = lw; bpad = pad; }
+    }
+    if ((double)bpad > 1.15 * (double)active) return plain;
+    g.map = tri ? TM_FOLD : TM_RECT;
+    g.mw = W; g.mh = H; g.msw = bw; g.msh = 6 - bw; g.mnsx = (W + (1 << bw) - 1) >> bw;
+    g.mfull = (int)((bpad / 512) * 512);
+    g.mnt = nte;
+    return dim3((unsigned)bpad, 1, zdim);
+}
+
 template <class T, int BM, int BN>
-static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits) {
-    constexpr int BK = (BM * BN <= 64 * 32) ? BKS : BKL;
+static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map) {
+    constexpr int BK = (BM * BN <= 32 * 32) ? BKS : BKL;
     GemmArgs<T> g = g_in;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
-    dim3 grid(tm, tn, splits);
-    g.tri = 0;
-    if (g.epi.uplo != 0 && BM == BN && tm == tn) {
-        g.tri = 1;
-        grid = dim3((unsigned)((long)tm * (tm + 1) / 2), 1, splits);
-    }
-    dim3 block(256);
-    int ta = g.A.trans, tb = g.B.trans;
-    const bool cat = g.A.k1 != INT_MAX || g.B.k1 != INT_MAX;
-    const bool cat_ok = !cat || (g.A.k1 == g.B.k1 && g.A.k1 % BK == 0);
-    if (g_use_fast && cat_ok) {
-        const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
-        // experiment knob (profiles/r03_experiments.txt 11): dynamic LDS added to every product workgroup, i.e. ONE workgroup per CU
-        static const unsigned pad = getenv("EIGSOLVE_GEMM_LDSPAD") ? (unsigned)atoi(getenv("EIGSOLVE_GEMM_LDSPAD")) : 0u;
-#define EIG_LAUNCH_FAST(TA_, TB_)                                                                                        \
-    do {                                                                                                                 \
-        if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, pad, st, g);      \
-        else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, false>), grid, block, pad, st, g);            \
+    const bool tri = g.epi.uplo != 0 && BM == BN && tm == tn;
+    const dim3 grid = choose_map(g, tm, tn, tri, splits, use_map);
+    const dim3 block(256);
+    const int ta = g.A.trans, tb = g.B.trans;
+    const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
+#define EIG_LAUNCH_FAST(TA_, TB_)                                                                                      \
+    do {                                                                                                               \
+        if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, 0, st, g);      \
+        else hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, false>), grid, block, 0, st, g);            \
     } while (0)
-        if (ta == 0 && tb == 0) EIG_LAUNCH_FAST(0, 0);
-        else if (ta == 0 && tb == 1) EIG_LAUNCH_FAST(0, 1);
-        else if (ta == 1 && tb == 0) EIG_LAUNCH_FAST(1, 0);
-        else EIG_LAUNCH_FAST(1, 1);
+    if (ta == 0 && tb == 0) EIG_LAUNCH_FAST(0, 0);
+    else if (ta == 0 && tb == 1) EIG_LAUNCH_FAST(0, 1);
+    else if (ta == 1 && tb == 0) EIG_LAUNCH_FAST(1, 0);
+    else EIG_LAUNCH_FAST(1, 1);
 #undef EIG_LAUNCH_FAST
-        EIG_HIP(hipGetLastError());
-        return;
-    }
-    if (ta == 0 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 0, BK>), grid, block, 0, st, g);
-    else if (ta == 0 && tb == 1) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 0, 1, BK>), grid, block, 0, st, g);
-    else if (ta == 1 && tb == 0) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 0, BK>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<T, BM, BN, 1, 1, BK>), grid, block, 0, st, g);
     EIG_HIP(hipGetLastError());
 }
 
@@ -646,38 +508,10 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
     if (g.M <= 0 || g.N <= 0) return;
     // pick the largest tile that still yields about one workgroup per CU: a 64x64x64 complex
     // tile is ~256 dependent MFMAs per wave (~15 us), so small problems want many small tiles.
-    long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * splits;
-    if (g.epi.inplace == 1) {  // all of M inside one workgroup; narrow tiles along N for parallelism
-        if ((long)((g.N + 63) / 64) >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
-        else launch_gemm<T, 64, 32>(st, g, splits);
-        return;
-    }
-    if (g.epi.inplace == 2) {
-        if ((long)((g.M + 63) / 64) >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
-        else launch_gemm<T, 32, 64>(st, g, splits);
-        return;
-    }
-    static const int tile_knob = getenv("EIGSOLVE_GEMM_TILE") ? atoi(getenv("EIGSOLVE_GEMM_TILE")) : 0;  // experiments only
-    if (tile_knob == 32) { launch_gemm<T, 32, 32>(st, g, splits); return; }
-    if constexpr (Tr<T>::cx) {
-        if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
-        else launch_gemm<T, 32, 32>(st, g, splits);
-    } else {
-        long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * splits;
-        // 128x128 real tiles measured slower than 64x64 on this part (dgemm 4096^3: 35.1 vs 40.8 TFLOP/s; dsygvdx
-        // N=8192: 306 vs 294 ms): kept for experiments only (EIGSOLVE_GEMM_128=1)
-        static const bool use128 = getenv("EIGSOLVE_GEMM_128") != nullptr;
-        // 128x64 tiles (each wave 64x32: 40 % fewer LDS fragment reads per MFMA than 32x32, still 2 workgroups per CU):
-        // dgemm 4096^3 40.8 -> 43.3 TFLOP/s, but inside the solver (triangular and mid-size shapes) 64x64 wins
-        // (dsygvdx N=8192: 294 vs 301 ms), so off by default.  The real engine is LDS-read bound (3.0 LDS-active
-        // cycles per MFMA against 1.5 for complex, where one fragment pair feeds four MFMAs).
-        static const bool use12864 = getenv("EIGSOLVE_GEMM_12864") != nullptr;
-        long tiles12864 = (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * splits;
-        if (use128 && tiles128 >= 2L * c.n_cu) launch_gemm<T, 128, 128>(st, g, splits);
-        else if (use12864 && tiles12864 >= 2L * c.n_cu) launch_gemm<T, 128, 64>(st, g, splits);
-        else if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits);
-        else launch_gemm<T, 32, 32>(st, g, splits);
-    }
+    // (128x128 and 128x64 real tiles were measured in rounds 2-3 and lost inside the solver; they are gone.)
+    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * splits;
+    if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0);
+    else launch_gemm<T, 32, 32>(st, g, splits, c.tile_map != 0);
 }
 
 template <class T>
@@ -691,9 +525,8 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
     // 512 slots: 2 rounds for 1.03 rounds of work).  When K is long enough, split it so that the work items are
     // short and many; the partial sums cost one pass over C and one more launch.
     if constexpr (Tr<T>::cx) {
-        static const bool auto_on = getenv("EIGSOLVE_GEMM_AUTOSPLIT") ? atoi(getenv("EIGSOLVE_GEMM_AUTOSPLIT")) != 0 : true;
         const bool masked = A.mask != M_NONE || Bt.mask != M_NONE;
-        if (auto_on && !masked && epi.inplace == 0 && K >= 1024) {
+        if (!masked && K >= 1024) {
             const long tm = (M + 63) / 64, tn = (N + 63) / 64, tmin = tm < tn ? tm : tn;
             long tiles = tm * tn;
             if (epi.uplo != 0) tiles = tmin * (tmin + 1) / 2 + (epi.uplo == 1 ? (tn - tmin) * tm : (tm - tmin) * tn);
@@ -780,6 +613,7 @@ void gemm_batched(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Op
         EIG_HIP(hipGetLastError());
     }
 }
+
 
 template <class T> void her2k_un(Ctx& c, hipStream_t st, int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc) {
     if (n <= 0 || k <= 0) return;
@@ -1209,57 +1043,9 @@ template <class T> __global__ void __launch_bounds__(256) place_inv64_kernel(int
     }
 }
 
-// P = -L M R for one s x s off-diagonal block of every 256-group (s = 64: blocks (0,1) and (2,3); s = 128: block
-// (01, 23)); L, R = the already merged inverse diagonal blocks (upper triangular), M from U.  One workgroup per
-// 32-column panel of P; Y = M R[:, panel] goes through LDS.
-template <class T> __global__ void __launch_bounds__(256) tri_merge_kernel(int s, T* inv256, const T* U, int ldu, int N, int g0) {
-    __shared__ T Ps[128][33];   // R panel, then the Y panel: [p][c]
-    const int g = g0 + blockIdx.y, pc = blockIdx.x, z = blockIdx.z;
-    const int r0 = (s == 64) ? z * 128 : 0, c0 = r0 + s;
-    T* G = inv256 + (size_t)g * BB * BB;
-    const int k0 = g * BB;
-    const int tid = threadIdx.x;
-    // one lane per row (coalesced column loads of M and L), 256/s column slices of the 32-column panel
-    const int r = tid % s, part = tid / s, cw = 32 / (256 / s), cb = part * cw;
-    for (int e = tid; e < s * 32; e += 256) {
-        const int pp = e % s, cc = e / s;
-        Ps[pp][cc] = G[(size_t)(c0 + pp) + (size_t)(c0 + pc * 32 + cc) * BB];   // zero below the diagonal (memset)
-    }
-    __syncthreads();
-    T acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = Tr<T>::zero();
-    const int gr = k0 + r0 + r;
-    const int pend = min(s, pc * 32 + 32);   // R is upper triangular: rows beyond the panel's last column are zero
-#pragma unroll 4
-    for (int pp = 0; pp < pend; ++pp) {
-        const int gc = k0 + c0 + pp;
-        const bool ok = gr < N && gc < N;
-        const T mv = sel(ok, U[(size_t)min(gr, N - 1) + (size_t)min(gc, N - 1) * ldu], Tr<T>::zero());
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < cw) fma_(acc[q], mv, Ps[pp][cb + q]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-        if (q < cw) { Ps[r][cb + q] = acc[q]; acc[q] = Tr<T>::zero(); }
-    __syncthreads();
-#pragma unroll 4
-    for (int pp = 0; pp < s; ++pp) {
-        const T lv = G[(size_t)(r0 + r) + (size_t)(r0 + pp) * BB];   // zero for pp < r
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < cw) fma_(acc[q], lv, Ps[pp][cb + q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-        if (q < cw) G[(size_t)(r0 + r) + (size_t)(c0 + pc * 32 + cb + q) * BB] = -acc[q];
-}
-
 // groups g0 .. g0+ng-1 (their 64-block inverses must be complete).  The merges P = -L M R are two strided-batch MFMA products
 // per off-diagonal block position (X = M R, P = -L X over all groups at once): 6 small launches, ~50 us for N = 4096, where
-// the round-1 one-lane-per-row kernel (tri_merge_kernel, kept for reference) took 2 x 150 us.
+// the round-1 one-lane-per-row kernel took 2 x 150 us.
 template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N, const T* U, int ldu, int g0, int ng) {
     const int nblk64 = (N + DB - 1) / DB, ngall = (N + BB - 1) / BB;
     if (ng <= 0) return;
@@ -1268,13 +1054,6 @@ template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N
     EIG_HIP(hipMemsetAsync(inv256 + (size_t)g0 * BB * BB, 0, sizeof(T) * (size_t)ng * BB * BB, st));
     hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256, g0);
     EIG_HIP(hipGetLastError());
-    static const bool old_merge = getenv("EIGSOLVE_TRI_MERGE_OLD") != nullptr;
-    if (old_merge) {
-        hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(64 / 32, ng, 2), dim3(256), 0, st, 64, inv256, U, ldu, N, g0);
-        hipLaunchKernelGGL((tri_merge_kernel<T>), dim3(128 / 32, ng, 1), dim3(256), 0, st, 128, inv256, U, ldu, N, g0);
-        EIG_HIP(hipGetLastError());
-        return;
-    }
     T* X = c.scratch<T>("inv_X", (size_t)ngall * 128 * 128);
     T* G0 = inv256 + (size_t)g0 * BB * BB;
     const size_t k00 = (size_t)g0 * BB;
@@ -1372,79 +1151,60 @@ template <class T> void build_inv_blocks(Ctx& c, hipStream_t st, int N, const T*
     if (base >= 512) build_inv_level<T>(c, st, N, U, ldu, 512);
     if (base >= 1024) build_inv_level<T>(c, st, N, U, ldu, 1024);
 }
-// result of a 256-base product goes through scratch (row blocks of the result are other workgroups' operands)
-template <class T> static void copy_back(hipStream_t st, const T* tmp, int ldt, T* X, int ldx, int rows, int cols) {
-    EIG_HIP(hipMemcpy2DAsync(X, sizeof(T) * ldx, tmp, sizeof(T) * ldt, sizeof(T) * rows, cols, hipMemcpyDeviceToDevice, st));
+// ---- triangular solves, out of place --------------------------------------------------------------------------------------
+// Y = op(U)^-1 X  /  Y = X U^-1 by recursive halving down to the inverted diagonal blocks.  The result goes to Y and X is the
+// workspace (its not yet solved blocks receive the updates): base-case products read X and write Y, updates read Y and
+// modify X.  The in-place form of rounds 1-3 had to stage every base-case product through scratch and copy it back (row
+// blocks of the result are other workgroups' operands): 80 rectangular copies of ~6 us per C3 solve.
+template <class T> static Operand<T> op_invbase(Ctx& c, int base, int k0, int trans, int conj) {
+    if (base == DB) return op_inv(c.scratch<T>("invU", 0) + (size_t)(k0 / DB) * DB * DB, trans, conj);
+    return op_invbig<T>(c, base, k0, trans, conj);
 }
 
-template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
+template <class T>
+void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base) {
     if (n <= 0 || m <= 0) return;
-    const T* invU = c.scratch<T>("invU", 0);
     base = norm_base(base);
     if (n <= base) {
-        if (base == DB) {
-            Epi e; e.inplace = 1;
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 0, 0), opB('N', X, ldx),
-                    Tr<T>::zero(), X, ldx, e);
-        } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbig<T>(c, base, k0, 0, 0), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
-            copy_back(st, tmp, n, X, ldx, n, m);
-        }
+        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbase<T>(c, base, k0, 0, 0), opB('N', (const T*)X, ldx), Tr<T>::zero(), Y, ldy);
         return;
     }
     int n1 = split_n1(n, base), n2 = n - n1;
-    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, base);
+    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, Y + n1, ldy, base);                  // Y2 = U22^-1 X2
     gemm<T>(c, st, n1, m, n2, Tr<T>::make(-1.0, 0.0), opA('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
-            opB('N', X + n1, ldx), Tr<T>::one(), X, ldx);
-    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx, base);
+            opB('N', (const T*)(Y + n1), ldy), Tr<T>::one(), X, ldx);                          // X1 -= U12 Y2
+    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx, Y, ldy, base);                                 // Y1 = U11^-1 X1
 }
 
-template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
+template <class T>
+void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base) {
     if (n <= 0 || m <= 0) return;
-    const T* invU = c.scratch<T>("invU", 0);
     base = norm_base(base);
     if (n <= base) {
-        if (base == DB) {
-            Epi e; e.inplace = 1;
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 1), opB('N', X, ldx),
-                    Tr<T>::zero(), X, ldx, e);
-        } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
-            gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbig<T>(c, base, k0, 1, 1), opB('N', X, ldx), Tr<T>::zero(), tmp, n);
-            copy_back(st, tmp, n, X, ldx, n, m);
-        }
+        gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbase<T>(c, base, k0, 1, 1), opB('N', (const T*)X, ldx), Tr<T>::zero(), Y, ldy);
         return;
     }
     int n1 = split_n1(n, base), n2 = n - n1;
-    trsm_LUC(c, st, n1, m, U, ldu, k0, X, ldx, base);
+    trsm_LUC(c, st, n1, m, U, ldu, k0, X, ldx, Y, ldy, base);                                 // Y1 = U11^-H X1
     gemm<T>(c, st, n2, m, n1, Tr<T>::make(-1.0, 0.0), opA('C', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
-            opB('N', X, ldx), Tr<T>::one(), X + n1, ldx);
-    trsm_LUC(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, base);
+            opB('N', (const T*)Y, ldy), Tr<T>::one(), X + n1, ldx);                            // X2 -= U12^H Y1
+    trsm_LUC(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, Y + n1, ldy, base);                  // Y2 = U22^-H X2
 }
 
-// X is m x n (m rows), solve X <- X U^-1 with U = U(k0:k0+n, k0:k0+n)
-template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, int base) {
+// X, Y are m x n (m rows): Y = X U^-1 with U = U(k0:k0+n, k0:k0+n)
+template <class T>
+void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base) {
     if (n <= 0 || m <= 0) return;
-    const T* invU = c.scratch<T>("invU", 0);
     base = norm_base(base);
     if (n <= base) {
-        if (base == DB) {
-            Epi e; e.inplace = 2;
-            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_inv(invU + (size_t)(k0 / DB) * DB * DB, 1, 0),
-                    Tr<T>::zero(), X, ldx, e);
-        } else {
-            T* tmp = c.scratch<T>("trsm_tmp", (size_t)base * m);
-            gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', X, ldx), op_invbig<T>(c, base, k0, 1, 0), Tr<T>::zero(), tmp, m);
-            copy_back(st, tmp, m, X, ldx, m, n);
-        }
+        gemm<T>(c, st, m, n, n, Tr<T>::one(), opA('N', (const T*)X, ldx), op_invbase<T>(c, base, k0, 1, 0), Tr<T>::zero(), Y, ldy);
         return;
     }
     int n1 = split_n1(n, base), n2 = n - n1;
-    trsm_RUN(c, st, n1, m, U, ldu, k0, X, ldx, base);
-    gemm<T>(c, st, m, n2, n1, Tr<T>::make(-1.0, 0.0), opA('N', X, ldx),
-            opB('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu), Tr<T>::one(), X + (size_t)n1 * ldx, ldx);
-    trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx, base);
+    trsm_RUN(c, st, n1, m, U, ldu, k0, X, ldx, Y, ldy, base);                                 // Y1 = X1 U11^-1
+    gemm<T>(c, st, m, n2, n1, Tr<T>::make(-1.0, 0.0), opA('N', (const T*)Y, ldy),
+            opB('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu), Tr<T>::one(), X + (size_t)n1 * ldx, ldx);   // X2 -= Y1 U12
+    trsm_RUN(c, st, n2, m, U, ldu, k0 + n1, X + (size_t)n1 * ldx, ldx, Y + (size_t)n1 * ldy, ldy, base);          // Y2 = X2 U22^-1
 }
 
 // use256: block boundaries above 256 fall on multiples of 256, every finished 256-block gets its merged inverse at
@@ -1463,7 +1223,11 @@ static void potrf_rec(Ctx& c, hipStream_t st, int Ntot, int n, int k0, T* B, int
     potrf_rec(c, st, Ntot, n1, k0, B, ldb, invU, use256, big && n1 <= BB);
     T* B12 = B + (size_t)k0 + (size_t)(k0 + n1) * ldb;
     T* B22 = B + (size_t)(k0 + n1) + (size_t)(k0 + n1) * ldb;
-    trsm_LUC(c, st, n1, n2, B, ldb, k0, B12, ldb, big ? BB : DB);
+    {   // B12 <- U11^-H B12 (the recursive form is the fallback without an intra-grid dependency, not the fast path: one staging copy)
+        T* tmp = c.scratch<T>("potrf_tmp", (size_t)Ntot * Ntot / 4 + 64);
+        trsm_LUC(c, st, n1, n2, B, ldb, k0, B12, ldb, tmp, n1, big ? BB : DB);
+        EIG_HIP(hipMemcpy2DAsync(B12, sizeof(T) * ldb, tmp, sizeof(T) * n1, sizeof(T) * n1, n2, hipMemcpyDeviceToDevice, st));
+    }
     Epi e; e.uplo = 1; e.herm_diag = 1;
     gemm<T>(c, st, n2, n2, n1, Tr<T>::make(-1.0, 0.0), opA('C', (const T*)B12, ldb), opB('N', (const T*)B12, ldb),
             Tr<T>::one(), B22, ldb, e);
@@ -1548,50 +1312,7 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
     build_invU_range<T>(c, st, N, U, ldu, 0, (N + DB - 1) / DB);
 }
 
-template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu) {
-    if (n <= 0) return;
-    const T* invU = c.scratch<T>("invU", 0);
-    if (n <= DB) {
-        hipLaunchKernelGGL((hegs2_block_kernel<T>), dim3(1), dim3(256), 0, st, n, A + (size_t)k0 + (size_t)k0 * lda, lda,
-                           invU + (size_t)(k0 / DB) * DB * DB);
-        EIG_HIP(hipGetLastError());
-        return;
-    }
-    int n1 = split_n1(n), n2 = n - n1;
-    hegst_rec(c, st, n1, k0, A, lda, U, ldu);
-    T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
-    T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
-    T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
-    const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
-    const T mhalf = Tr<T>::make(-0.5, 0.0);
-    // A12 <- U11^-H A12                                   (zhegst_gpu.F90:87-88)
-    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda);
-    auto hemm_half = [&]() {
-        // A12 -= 1/2 Herm(A11) U12, Herm(A11) = triu(A11) + striu(A11)^H: two K-trimmed gemms
-        Operand<T> up = op_plain((const T*)A11, lda, 0, 0);
-        up.mask = M_UPPER;
-        Operand<T> lo = op_plain((const T*)A11, lda, 1, 1);
-        lo.mask = M_SUPPER;
-        gemm<T>(c, st, n1, n2, n1, mhalf, up, opB('N', U12, ldu), Tr<T>::one(), A12, lda);
-        gemm<T>(c, st, n1, n2, n1, mhalf, lo, opB('N', U12, ldu), Tr<T>::one(), A12, lda);
-    };
-    hemm_half();  // :93-94
-    {
-        // A22 -= A12^H U12 + U12^H A12 (upper)              (:95-96), one pass over A22
-        Operand<T> Ao, Bo;
-        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
-        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
-        Epi e; e.uplo = 1; e.herm_diag = 1;
-        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
-    }
-    hemm_half();  // :100-101
-    // A12 <- A12 U22^-1                                   (:103-104)
-    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda);
-    hegst_rec(c, st, n2, k0 + n1, A, lda, U, ldu);
-}
-
-template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
-
+// ---- reduction to standard form --------------------------------------------------------------------------------------------
 // hegst on a stream of its own, released stage by stage as block rows of the factor complete on the factorization's stream
 // (potrf || hegst pipeline below): need(r) = "the next operation reads rows < r of U (and their inverse diagonal blocks)".
 constexpr int kStageRows = 1024;
@@ -1604,27 +1325,7 @@ struct UGate {
         while (have < s_) EIG_HIP(hipStreamWaitEvent(st, ev[have++], 0));
     }
 };
-template <class T>
-static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr, UGate* gate = nullptr);
-template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
-template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
-    // EIGSOLVE_GST: 0 = symmetric recursion down to 64x64 blocks (2/3 N^3 multiply-adds, ~16N/64 small launches),
-    //               1 = two full triangular solves (N^3 multiply-adds, ~4N/64 large launches),
-    //               2 = hybrid (default): the symmetric algorithm (zhegst_gpu.F90:51-107) on the large levels, where
-    //                   every operation is a chip-filling MFMA launch, two solves on diagonal blocks of order
-    //                   <= EIGSOLVE_GST_THR (1024).  C3 (N=4096): 28.3 / 14.2 / 11.0 ms with the 256-block inverses.
-    const int mode = c.gst_mode, thr = c.gst_thr;   // EIGSOLVE_GST / EIGSOLVE_GST_THR, eigsolve_set_option("gst" / "gst_thr")
-    if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
-    else if (mode == 3) hegst_blocked(c, st, N, A, lda, U, ldu);
-    else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
-    else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr);
-}
-
-// ---- hegst as two full triangular solves ------------------------------------------------------------
-// F = Herm(A) (completed copy), F <- U^-H F, F <- F U^-1, upper(A) <- upper(F).  2x the flops of the
-// symmetric algorithm (zhegst_gpu.F90:51-107) but ~4N/64 large launches instead of ~16N/64 small ones:
-// on MI355X the small-launch chain, not the flops, dominates the symmetric form.
 template <class T> __global__ void __launch_bounds__(256) herm_complete_kernel(int n, const T* A, int lda, T* F, int ldf) {
     __shared__ T tile[32][33];
     const int bx = blockIdx.x, by = blockIdx.y;   // tile (bx = row block, by = col block), only bx <= by launched work
@@ -1654,20 +1355,119 @@ template <class T> __global__ void __launch_bounds__(256) copy_upper_kernel(int 
     if (r == cc) v = Tr<T>::realpart(v);
     A[(size_t)r + (size_t)cc * lda] = v;
 }
+// Y(rows x cols, ldy) += X(rows x cols, ldx)
+template <class T> __global__ void __launch_bounds__(256) add_block_kernel(int rows, int cols, const T* X, int ldx, T* Y, int ldy) {
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)rows * cols) return;
+    const int r = (int)(id % rows), cc = (int)(id / rows);
+    Y[(size_t)r + (size_t)cc * ldy] = Y[(size_t)r + (size_t)cc * ldy] + X[(size_t)r + (size_t)cc * ldx];
+}
+
+// ---- hegst as two full triangular solves ------------------------------------------------------------
+// F = Herm(A) (completed copy), G = U^-H F, F = G U^-1, upper(A) <- upper(F).  2x the flops of the
+// symmetric algorithm (zhegst_gpu.F90:51-107) but ~4N/64 large launches instead of ~16N/64 small ones:
+// on MI355X the small-launch chain, not the flops, dominates the symmetric form.
 template <class T> static void hegst_two_solves_at(Ctx& c, hipStream_t st, int N, int k0, T* A, int lda, const T* U, int ldu) {
     if (N <= 0) return;
     T* Ablk = A + (size_t)k0 + (size_t)k0 * lda;
     T* F = c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", (size_t)N * N);
+    T* G = c.scratch<T>(Tr<T>::cx ? "gst_Gz" : "gst_Gd", (size_t)N * N);
     const int nb32 = (N + 31) / 32;
     hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)Ablk, lda, F, N);
-    trsm_LUC(c, st, N, N, U, ldu, k0, F, N, c.trsm_base);   // F <- U(k0.., k0..)^-H F
-    trsm_RUN(c, st, N, N, U, ldu, k0, F, N, c.trsm_base);   // F <- F U(k0.., k0..)^-1
+    trsm_LUC(c, st, N, N, U, ldu, k0, F, N, G, N, c.trsm_base);   // G = U(k0.., k0..)^-H F
+    trsm_RUN(c, st, N, N, U, ldu, k0, G, N, F, N, c.trsm_base);   // F = G U(k0.., k0..)^-1
     size_t tot = (size_t)N * N;
     hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, Ablk, lda);
     EIG_HIP(hipGetLastError());
 }
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
     hegst_two_solves_at(c, st, N, 0, A, lda, U, ldu);
+}
+
+// The block step of the symmetric algorithm (zhegst_gpu.F90:85-104) for the leading block [k0, k0+n1) against the n2
+// columns to its right, A11 already reduced:
+//     A12 <- U11^-H A12                      (:87-88)
+//     A12 -= 1/2 Herm(A11) U12               (:93-94)
+//     A22 -= A12^H U12 + U12^H A12 (upper)   (:95-96)
+//     A12 -= 1/2 Herm(A11) U12               (:100-101)
+//     A12 <- A12 U22^-1                      (:103-104)
+// The reference (like LAPACK's zhegst) forms the product Herm(A11) U12 twice to save workspace; here it is formed ONCE --
+// the first application also stores -1/2 Herm(A11) U12 (Epi::aux), the second is an addition -- which removes a sixth of the
+// multiply-adds of hegst.  The two solves are out of place (A12 -> T -> A12), so nothing is staged or copied.
+template <class T>
+static void hegst_block_step(Ctx& c, hipStream_t st, int n1, int n2, int k0, T* A, int lda, const T* U, int ldu, int base, UGate* gate) {
+    T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
+    T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
+    T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
+    const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
+    T* Tm = c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", (size_t)n1 * n2);
+    T* Xh = c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", (size_t)n1 * n2);
+    T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
+    if (gate) gate->need(k0 + n1);                                     // the next four steps read U(k0 : k0+n1, :) only
+    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda, Tm, n1, base);      // T = U11^-H A12
+    {
+        const int nb32 = (n1 + 31) / 32;                               // Herm(A11) completed once: the product is a plain full-rate gemm
+        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
+    }
+    {
+        Epi e; e.aux = Xh; e.ldaux = n1;                               // T -= 1/2 Herm(A11) U12,  Xh = -1/2 Herm(A11) U12
+        gemm<T>(c, st, n1, n2, n1, Tr<T>::make(-0.5, 0.0), opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), Tm, n1, e);
+    }
+    {
+        Operand<T> Ao, Bo;                                             // A22 -= T^H U12 + U12^H T (upper), one pass over A22
+        Ao.p = Tm; Ao.ld = n1; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
+        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = Tm; Bo.ld2 = n1;
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
+    }
+    {
+        const size_t tot = (size_t)n1 * n2;                            // T += Xh
+        hipLaunchKernelGGL((add_block_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n1, n2, (const T*)Xh, n1, Tm, n1);
+    }
+    if (gate) gate->need(k0 + n1 + n2);                                // U22 from here on
+    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, Tm, n1, A12, lda, base); // A12 = T U22^-1
+    EIG_HIP(hipGetLastError());
+}
+
+// symmetric recursion down to the 64x64 blocks (gst = 0, and every order below 256)
+template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu) {
+    if (n <= 0) return;
+    const T* invU = c.scratch<T>("invU", 0);
+    if (n <= DB) {
+        hipLaunchKernelGGL((hegs2_block_kernel<T>), dim3(1), dim3(256), 0, st, n, A + (size_t)k0 + (size_t)k0 * lda, lda,
+                           invU + (size_t)(k0 / DB) * DB * DB);
+        EIG_HIP(hipGetLastError());
+        return;
+    }
+    int n1 = split_n1(n), n2 = n - n1;
+    hegst_rec(c, st, n1, k0, A, lda, U, ldu);
+    hegst_block_step<T>(c, st, n1, n2, k0, A, lda, U, ldu, DB, nullptr);
+    hegst_rec(c, st, n2, k0 + n1, A, lda, U, ldu);
+}
+
+template <class T>
+static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr, UGate* gate = nullptr);
+template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
+
+template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
+    // option "gst": 0 = symmetric recursion down to 64x64 blocks (~16N/64 small launches),
+    //               1 = two full triangular solves (N^3 multiply-adds, ~4N/64 large launches),
+    //               2 = hybrid (default): the symmetric algorithm (zhegst_gpu.F90:51-107) on the large levels, where
+    //                   every operation is a chip-filling MFMA launch, two solves on diagonal blocks of order
+    //                   <= "gst_thr" (1024),
+    //               3 = the reference's loop with nb = the order of the inverse diagonal blocks.
+    const int mode = c.gst_mode, thr = c.gst_thr;
+    // (grow the scratch slots of the block steps to their largest size up front: the recursion asks for the small ones first)
+    if (N > 1) {
+        const size_t q = (size_t)N * N / 4 + 64;
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", q);
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", q);
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", q);
+    }
+    if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
+    else if (mode == 3) hegst_blocked(c, st, N, A, lda, U, ldu);
+    else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
+    else hegst_hybrid(c, st, N, 0, A, lda, U, ldu, thr);
 }
 
 // One level of the symmetric algorithm (zhegst_gpu.F90:51-107 with the block size = half the matrix): every
@@ -1683,65 +1483,20 @@ static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, c
     }
     int n1 = split_n1(n, gran), n2 = n - n1;   // block boundaries must match the inverse diagonal blocks
     hegst_hybrid(c, st, n1, k0, A, lda, U, ldu, thr, gate);
-    T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
-    T* A12 = A + (size_t)k0 + (size_t)(k0 + n1) * lda;
-    T* A22 = A + (size_t)(k0 + n1) + (size_t)(k0 + n1) * lda;
-    const T* U12 = U + (size_t)k0 + (size_t)(k0 + n1) * ldu;
-    const T mhalf = Tr<T>::make(-0.5, 0.0);
-    if (gate) gate->need(k0 + n1);                                     // the next four steps read U(k0 : k0+n1, :) only
-    trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda, c.trsm_base);        // A12 <- U11^-H A12
-    // Herm(A11) completed once into scratch: the two hemm steps are then plain full-rate gemms
-    T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)n1 * n1);
-    {
-        const int nb32 = (n1 + 31) / 32;
-        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
-    }
-    auto hemm_half = [&]() {                                          // A12 -= 1/2 Herm(A11) U12
-        gemm<T>(c, st, n1, n2, n1, mhalf, opA('N', (const T*)H, n1), opB('N', U12, ldu), Tr<T>::one(), A12, lda);
-    };
-    hemm_half();
-    {
-        Operand<T> Ao, Bo;                                            // A22 -= A12^H U12 + U12^H A12 (upper)
-        Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = n1; Ao.p2 = U12; Ao.ld2 = ldu;
-        Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = n1; Bo.p2 = A12; Bo.ld2 = lda;
-        Epi e; e.uplo = 1; e.herm_diag = 1;
-        gemm<T>(c, st, n2, n2, 2 * n1, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
-    }
-    hemm_half();
-    if (gate) gate->need(k0 + n);                                      // U22 from here on
-    trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, A12, lda, c.trsm_base);  // A12 <- A12 U22^-1
+    hegst_block_step<T>(c, st, n1, n2, k0, A, lda, U, ldu, c.trsm_base, gate);
     hegst_hybrid(c, st, n2, k0 + n1, A, lda, U, ldu, thr, gate);
 }
 
 // The reference's own loop (zhegst_gpu.F90:51-107) with block size nb = the order of the inverse diagonal blocks
-// ("trsm_base" 512 / 1024): per block step the diagonal block by two products with its inverse, then
-// trsm / hemm / her2k / hemm / trsm on the block row -- (1/2 + O(nb/N)) N^3 multiply-adds instead of the ~2/3 N^3 of
-// the half-split recursion.
+// ("trsm_base" 512 / 1024): per block step the diagonal block by two products with its inverse, then the block step above on
+// the block row -- (1/2 + O(nb/N)) N^3 multiply-adds instead of the ~2/3 N^3 of the half-split recursion.
 template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
     const int base = norm_base(c.trsm_base), nb = base < 256 ? 256 : base;
-    const T mhalf = Tr<T>::make(-0.5, 0.0);
     for (int k0 = 0; k0 < N; k0 += nb) {
         const int kb = min(nb, N - k0), rest = N - k0 - kb;
         hegst_two_solves_at(c, st, kb, k0, A, lda, U, ldu);                          // :57-83
         if (rest <= 0) break;
-        T* A11 = A + (size_t)k0 + (size_t)k0 * lda;
-        T* A12 = A + (size_t)k0 + (size_t)(k0 + kb) * lda;
-        T* A22 = A + (size_t)(k0 + kb) + (size_t)(k0 + kb) * lda;
-        const T* U12 = U + (size_t)k0 + (size_t)(k0 + kb) * ldu;
-        trsm_LUC(c, st, kb, rest, U, ldu, k0, A12, lda, base);                       // :87-88
-        T* H = c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", (size_t)kb * kb);
-        const int nb32 = (kb + 31) / 32;
-        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, kb, (const T*)A11, lda, H, kb);
-        gemm<T>(c, st, kb, rest, kb, mhalf, opA('N', (const T*)H, kb), opB('N', U12, ldu), Tr<T>::one(), A12, lda);   // :93-94
-        {
-            Operand<T> Ao, Bo;                                                       // :95-96
-            Ao.p = A12; Ao.ld = lda; Ao.trans = 1; Ao.conj = 1; Ao.k1 = kb; Ao.p2 = U12; Ao.ld2 = ldu;
-            Bo.p = U12; Bo.ld = ldu; Bo.trans = 1; Bo.conj = 0; Bo.k1 = kb; Bo.p2 = A12; Bo.ld2 = lda;
-            Epi e; e.uplo = 1; e.herm_diag = 1;
-            gemm<T>(c, st, rest, rest, 2 * kb, Tr<T>::make(-1.0, 0.0), Ao, Bo, Tr<T>::one(), A22, lda, e);
-        }
-        gemm<T>(c, st, kb, rest, kb, mhalf, opA('N', (const T*)H, kb), opB('N', U12, ldu), Tr<T>::one(), A12, lda);   // :100-101
-        trsm_RUN(c, st, rest, kb, U, ldu, k0 + kb, A12, lda, base);                  // :103-104
+        hegst_block_step<T>(c, st, kb, rest, k0, A, lda, U, ldu, base, nullptr);      // :87-104
     }
     EIG_HIP(hipGetLastError());
 }
@@ -1782,6 +1537,12 @@ template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda
     }
     // (everything above is queued before the first wait below is: a wait on an event that has not been recorded yet is a no-op)
     hipStream_t s2 = c.second_stream();
+    {   // the block steps' scratch at its largest size before anything of hegst is queued (the recursion asks for the small ones first)
+        const size_t q = (size_t)N * N / 4 + 64;
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", q);
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", q);
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", q);
+    }
     UGate gate{s2, c.evStage, 0};
     hegst_hybrid<T>(c, s2, N, 0, A, lda, (const T*)B, ldb, c.gst_thr, &gate);
     EIG_HIP(hipEventRecord(c.evB, s2));
@@ -1801,9 +1562,9 @@ template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, con
                                   Epi, GemmBatch, int);                                                                  \
     template void potrf_upper<T>(Ctx&, hipStream_t, int, T*, int);                                                       \
     template void build_invU<T>(Ctx&, hipStream_t, int, const T*, int);                                                  \
-    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
-    template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
-    template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, int);                            \
+    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
+    template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
+    template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
     template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \
     template void build_inv_blocks<T>(Ctx&, hipStream_t, int, const T*, int);                                            \
     template void hegst_upper<T>(Ctx&, hipStream_t, int, T*, int, const T*, int);                                        \

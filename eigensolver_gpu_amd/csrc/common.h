@@ -109,12 +109,6 @@ constexpr int kTridiagDefault = 1;
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 3;
-// Tridiagonalization: panels whose trailing order is at most this many rows take the one-launch-per-column kernel
-// (panel_col_kernel in trd.hip).  0 = never: measured in round 3, the launch it saves (4.8 us) costs more than that in
-// redundant row work -- 6.7-8.7 us per column in-kernel against 2 x 2.8 (profiles/r03_experiments.txt) -- so the two-kernel
-// form stays the default; option "trd_fuse" / EIGSOLVE_TRD_FUSE selects an order for experiments and the parity tests.
-constexpr int kTrdFuseZ = 0;
-constexpr int kTrdFuseD = 0;
 // Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
 constexpr int kGstModeDefault = 2;
@@ -146,15 +140,14 @@ struct Ctx {
     int trd_nb = 64;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
-    int p_wt = 0;         // 1: hemv partials stored write-through (sc1), see store_partial in trd.hip
-    int hemv_balance = 0; // 1: spread the hemv tiles evenly over the rounds (measured slower, see hemv_grid in trd.hip)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
     int in_batch = 0;        // set while this context solves one problem of a batch call with several problems in flight
-    int overlap = kOverlapDefault;   // bit 0: the latency-bound second half of potrf beside the part of hegst that only needs the
-                             // first half of the factor (potrf_hegst_pipelined_begin; only while no other solve is in flight);
-                             // bit 1: larft T factors on the second stream while the tridiagonal eigenproblem is solved
-                             // (zheevd_gpu.F90:125 overlaps the same work; measured: trd + 4 ms, off)
+    int overlap = kOverlapDefault;   // bit 0: hegst on a second stream beside the factorization, released stage by stage
+                             // (potrf_hegst_pipelined_begin); bit 1: the larft T factors on the second stream while the tridiagonal
+                             // eigenproblem is solved (zheevd_gpu.F90:125 overlaps the same work).  Both only for a solve that has the
+                             // device to itself -- a best-effort test (streams_in_use() sampled once per phase, not a lock: two caller
+                             // threads that start together may both decide they are alone; results are identical either way)
     struct GraphEntry {
         hipGraphExec_t exec = nullptr;
         hipGraph_t graph = nullptr;
@@ -167,7 +160,10 @@ struct Ctx {
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108
     int tridiag_device = kTridiagDefault;  // 0: host LAPACK dstedc (reference behaviour), 1: device divide & conquer
-    int trd_fuse = -1;       // >= 0: order below which panels use panel_col_kernel (0 = never); -1 = default per type
+    int trd_finish = -1;     // order at which the tridiagonalization hands the rest of the matrix to the one-workgroup LDS kernel
+                             // (hetd2_wide_kernel in trd.hip): -1 = the largest order its LDS holds, 32 = the reference's cut-over
+                             // (zhetrd_gpu.F90:84-87)
+    int tile_map = 1;        // 1: XCD-aware super-tile map of the MFMA engine's workgroups (tile_of in blas3.hip), 0: plain grids
     int batch_fuse = -1;     // problems per launch chain of a batch call that share the per-column launches of the tridiagonalization
                              // (lockstep groups of <= 4): -1 = automatic (groups while a matrix is <= 96 MiB), 1 = none
     int batch_workers = -1;  // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +
@@ -200,15 +196,17 @@ struct StreamLease {
     StreamLease(const StreamLease&) = delete;
     StreamLease& operator=(const StreamLease&) = delete;
 };
-void copy_options(Ctx& dst, const Ctx& src);
+void copy_options(Ctx& dst, const Ctx& src);   // all tunables of src (eigsolve_set_option / environment) into dst
+bool apply_option(Ctx& c, const std::string& name, int value);   // eigsolve_set_option / EIGSOLVE_<NAME>; false: unknown name
 int streams_in_use(int dev);   // API calls in flight on the device (leased compute streams)
-int auto_batch_workers();   // 4 when the process has asked for >= 5 hardware queues (GPU_MAX_HW_QUEUES), else 3   // all tunables of src (eigsolve_set_option / environment) into dst
+int auto_batch_workers();   // 4 when the process has asked for >= 5 hardware queues (GPU_MAX_HW_QUEUES), else 3
 
 // The library's own worker threads (context.cpp): runs fn(0) ... fn(ntasks-1) on `nworkers` of them, device `dev` current,
 // each worker taking the next task as it finishes one; returns when all are done.  A worker keeps its per-thread context
 // (stream, scratch) from call to call.
 void batch_run(int dev, int nworkers, int ntasks, const std::function<void(int)>& fn);
 void batch_workers_finalize(int dev);          // every worker releases its context for `dev`
+void stream_pool_finalize(int dev);            // idle pool streams of `dev` are destroyed
 
 // host LAPACK plumbing (context.cpp)
 stedc_fn get_dstedc();

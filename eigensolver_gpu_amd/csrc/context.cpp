@@ -128,7 +128,8 @@ void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
 }
 
 StreamLease::StreamLease(Ctx& ctx_) : c(ctx_) {
-    if (c.lease_depth++ == 0) c.s1 = lease_stream(c.dev, c.s1);
+    if (c.lease_depth == 0) c.s1 = lease_stream(c.dev, c.s1);   // may throw (hipStreamCreate): the depth is only counted on success
+    ++c.lease_depth;
 }
 StreamLease::~StreamLease() {
     if (--c.lease_depth == 0 && c.s1) {
@@ -207,10 +208,11 @@ int auto_batch_workers() {
 }
 
 void copy_options(Ctx& c, const Ctx& d) {
+    if (c.trd_nb != d.trd_nb || c.hemv_blocks != d.hemv_blocks) c.drop_graphs();   // baked into captured launch sequences
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
-    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
-    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.trd_fuse = d.trd_fuse; c.batch_fuse = d.batch_fuse;
+    c.tridiag_device = d.tridiag_device; c.real_il_reference = d.real_il_reference; c.tile_map = d.tile_map;
+    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.batch_fuse = d.batch_fuse; c.trd_finish = d.trd_finish;
 }
 
 // ---- the library's worker threads ------------------------------------------------------------------------------------
@@ -220,19 +222,49 @@ void copy_options(Ctx& c, const Ctx& d) {
 namespace {
 struct WorkerPool {
     std::mutex mu;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_done;
     std::deque<std::function<void()>> q;
     int nthreads = 0;
+    // eigsolve_finalize(dev): every worker thread releases its context for `dev`.  Requests are numbered (epoch); a thread
+    // handles the requests newer than the last one it has seen whenever it is between two tasks, and acknowledges.
+    unsigned rel_epoch = 0;
+    std::vector<std::pair<unsigned, int>> rel;   // (epoch, device)
+    int rel_acks = 0;
     void ensure(int n) {   // mu held
         while (nthreads < n) {
-            std::thread([this] {
+            const unsigned born = rel_epoch;
+            std::thread([this, born] {
+                unsigned seen = born;
                 for (;;) {
                     std::function<void()> f;
+                    std::vector<int> todo;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return !q.empty(); });
-                        f = std::move(q.front());
-                        q.pop_front();
+                        cv.wait(lk, [&] { return !q.empty() || rel_epoch != seen; });
+                        if (rel_epoch != seen) {
+                            for (auto& r : rel)
+                                if ((int)(r.first - seen) > 0) todo.push_back(r.second);
+                            seen = rel_epoch;
+                        } else {
+                            f = std::move(q.front());
+                            q.pop_front();
+                        }
+                    }
+                    if (!f) {
+                        for (int dev : todo) {
+                            auto it = t_ctx.m.find(dev);
+                            if (it == t_ctx.m.end()) continue;
+                            (void)hipSetDevice(dev);
+                            it->second->release();
+                            delete it->second;
+                            t_ctx.m.erase(it);
+                        }
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            ++rel_acks;
+                        }
+                        cv_done.notify_all();
+                        continue;
                     }
                     f();
                 }
@@ -245,6 +277,7 @@ WorkerPool& workers() {
     static WorkerPool* p = new WorkerPool();   // leaked on purpose: no destructor may run while a worker still waits on it
     return *p;
 }
+std::mutex g_finalize_mu;   // one eigsolve_finalize at a time (the acknowledgement count belongs to one request)
 }  // namespace
 
 void batch_run(int dev, int nworkers, int ntasks, const std::function<void(int)>& fn) {
@@ -288,66 +321,77 @@ void batch_run(int dev, int nworkers, int ntasks, const std::function<void(int)>
     call.cv.wait(lk, [&] { return call.running == 0; });
 }
 
+// Every worker thread of the library releases its context for `dev`; returns when all of them have (a worker that is in the
+// middle of another caller's batch task does so when that task ends).  Callers are serialised; no thread spins.
 void batch_workers_finalize(int dev) {
-    int n;
-    {
-        std::lock_guard<std::mutex> lk(workers().mu);
-        n = workers().nthreads;
-    }
+    std::lock_guard<std::mutex> fin(g_finalize_mu);
+    WorkerPool& wp = workers();
+    std::unique_lock<std::mutex> lk(wp.mu);
+    const int n = wp.nthreads;
     if (n == 0) return;
-    // one task per worker thread: a barrier inside makes sure every thread takes exactly one
-    // (the caller takes part in batch_run as a worker: n + 1 tasks for n pool threads + the caller, whose own context is
-    //  released by eigsolve_finalize right after)
-    std::atomic<int> arrived{0};
-    const std::thread::id me = std::this_thread::get_id();
-    batch_run(dev, n + 1, n + 1, [&](int) {
-        if (std::this_thread::get_id() != me) {
-            auto it = t_ctx.m.find(dev);
-            if (it != t_ctx.m.end()) {
-                it->second->release();
-                delete it->second;
-                t_ctx.m.erase(it);
-            }
-        }
-        arrived.fetch_add(1);
-        while (arrived.load() < n + 1) std::this_thread::yield();
-    });
+    ++wp.rel_epoch;
+    if (wp.rel.size() > 64) wp.rel.erase(wp.rel.begin(), wp.rel.begin() + 32);   // (every live thread has long seen those)
+    wp.rel.emplace_back(wp.rel_epoch, dev);
+    wp.rel_acks = 0;
+    wp.cv.notify_all();
+    wp.cv_done.wait(lk, [&] { return wp.rel_acks >= n; });
 }
 
-// tunables: compile-time defaults, overridden by the environment (eigsolve_set_option changes them per context afterwards)
+// idle streams of the pool for `dev` (nothing of the library runs on them: calls end synchronised)
+void stream_pool_finalize(int dev) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto& v = g_streams[dev];
+    for (size_t i = 0; i < v.size();) {
+        if (!v[i].busy) {
+            (void)hipStreamDestroy(v[i].s);
+            v.erase(v.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+}
+
+// ---- tunables ---------------------------------------------------------------------------------------------------------
+// One table: eigsolve_set_option(name, value) and the environment variable EIGSOLVE_<NAME> (read when a context is created;
+// same value semantics, plus the words "host" / "device" for TRIDIAG and "rec" for POTRF) go through apply_option.
+static const char* const kOptionNames[] = {"trd_nb", "bt_nb", "hemv_blocks", "real_il_reference", "graph", "overlap", "trsm_base",
+                                           "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "tridiag", "tile_map",
+                                           "trd_finish", "trace_marks"};
+bool apply_option(Ctx& c, const std::string& s, int value) {
+    if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? 64 : value; c.drop_graphs(); }
+    else if (s == "bt_nb") c.bt_nb = norm_bt_nb(value);
+    else if (s == "hemv_blocks") { c.hemv_blocks = value < 0 ? 0 : (value > kHemvBlocksMax ? kHemvBlocksMax : value); c.drop_graphs(); }
+    else if (s == "real_il_reference") c.real_il_reference = value > 0;
+    else if (s == "graph") c.use_graph = value > 0;
+    else if (s == "overlap") c.overlap = value < 0 ? kOverlapDefault : (value & 3);
+    else if (s == "trsm_base") c.trsm_base = value <= 0 ? kTrsmBaseDefault : norm_trsm_base(value);
+    else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
+    else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? kGstModeDefault : value;
+    else if (s == "gst_thr") c.gst_thr = value <= 0 ? kGstThrDefault : (value < 256 ? 256 : value);
+    else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;
+    else if (s == "batch_fuse") c.batch_fuse = (value < 1 || value > 4) ? -1 : value;
+    else if (s == "tridiag") c.tridiag_device = value < 0 ? kTridiagDefault : (value > 0 ? 1 : 0);
+    else if (s == "tile_map") c.tile_map = value != 0;
+    else if (s == "trd_finish") { c.trd_finish = value < 0 ? -1 : value; c.drop_graphs(); }
+    else if (s == "trace_marks") c.trace_marks = value > 0;
+    else return false;
+    return true;
+}
+
 static void init_options(Ctx& c) {
-    Ctx d;   // defaults
-    c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
-    c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
-    c.tridiag_device = d.tridiag_device; c.p_wt = d.p_wt; c.hemv_balance = d.hemv_balance; c.real_il_reference = d.real_il_reference;
-    c.batch_workers = d.batch_workers;
-    c.trd_fuse = d.trd_fuse;
-    if (const char* e = getenv("EIGSOLVE_TRD_FUSE")) c.trd_fuse = atoi(e);
-    if (c.trd_fuse > 8192) c.trd_fuse = 8192;
-    if (const char* e = getenv("EIGSOLVE_BATCH_WORKERS")) c.batch_workers = atoi(e);
-    c.batch_fuse = d.batch_fuse;
-    if (const char* e = getenv("EIGSOLVE_BATCH_FUSE")) c.batch_fuse = atoi(e);
-    if (c.batch_fuse < -1 || c.batch_fuse == 0 || c.batch_fuse > 4) c.batch_fuse = -1;
-    if (c.batch_workers < -1 || c.batch_workers > 16) c.batch_workers = d.batch_workers;
-    if (const char* e = getenv("EIGSOLVE_REAL_IL_REFERENCE")) c.real_il_reference = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_TRACE_MARKS")) c.trace_marks = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_TRD_NB")) c.trd_nb = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_BT_NB")) c.bt_nb = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_HEMV_BLOCKS")) c.hemv_blocks = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_P_WT")) c.p_wt = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_HEMV_BALANCE")) c.hemv_balance = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_GRAPH")) c.use_graph = atoi(e) != 0;
-    if (const char* e = getenv("EIGSOLVE_OVERLAP")) c.overlap = atoi(e) & 3;
-    if (const char* e = getenv("EIGSOLVE_TRSM_BASE")) c.trsm_base = norm_trsm_base(atoi(e));
-    if (const char* e = getenv("EIGSOLVE_POTRF")) c.potrf_mode = (e[0] == 'r' || e[0] == '0') ? 0 : 1;
-    if (const char* e = getenv("EIGSOLVE_GST")) c.gst_mode = atoi(e);
-    if (const char* e = getenv("EIGSOLVE_GST_THR")) c.gst_thr = atoi(e);
-    if (c.gst_mode < 0 || c.gst_mode > 3) c.gst_mode = kGstModeDefault;
-    if (c.gst_thr < 256) c.gst_thr = 256;
-    if (const char* e = getenv("EIGSOLVE_TRIDIAG")) c.tridiag_device = (e[0] == 'd' || e[0] == 'D' || e[0] == '1') ? 1 : 0;
-    if (c.trd_nb < 1 || c.trd_nb > 64) c.trd_nb = 64;
-    c.bt_nb = norm_bt_nb(c.bt_nb);
-    if (c.hemv_blocks > kHemvBlocksMax) c.hemv_blocks = kHemvBlocksMax;
+    Ctx d;   // compile-time defaults
+    copy_options(c, d);
+    c.trace_marks = 0;
+    for (const char* name : kOptionNames) {
+        std::string env = "EIGSOLVE_";
+        for (const char* p = name; *p; ++p) env += (char)toupper((unsigned char)*p);
+        const char* e = getenv(env.c_str());
+        if (!e || !*e) continue;
+        int v = atoi(e);
+        if (e[0] == 'h' || e[0] == 'H' || e[0] == 'r' || e[0] == 'R') v = 0;          // TRIDIAG=host, POTRF=rec
+        else if (e[0] == 'd' || e[0] == 'D') v = 1;                                      // TRIDIAG=device
+        (void)apply_option(c, name, v);
+    }
 }
 
 Ctx& ctx() {
@@ -489,10 +533,12 @@ int eigsolve_finalize(void) {
         }
     }
     auto it = eig::t_ctx.m.find(dev);
-    if (it == eig::t_ctx.m.end()) return 0;
-    it->second->release();
-    delete it->second;
-    eig::t_ctx.m.erase(it);
+    if (it != eig::t_ctx.m.end()) {
+        it->second->release();
+        delete it->second;
+        eig::t_ctx.m.erase(it);
+    }
+    eig::stream_pool_finalize(dev);
     return 0;
 }
 
@@ -508,26 +554,7 @@ int eigsolve_set_host_threads(int n) {
 
 int eigsolve_set_option(const char* name, int value) {
     try {
-        eig::Ctx& c = eig::ctx();
-        std::string s(name ? name : "");
-        if (s == "trd_nb") c.trd_nb = (value <= 0 || value > 64) ? 64 : value;
-        else if (s == "bt_nb") c.bt_nb = eig::norm_bt_nb(value);
-        else if (s == "hemv_blocks") c.hemv_blocks = value < 0 ? 0 : (value > eig::kHemvBlocksMax ? eig::kHemvBlocksMax : value);
-        else if (s == "hemv_balance") { c.hemv_balance = value < 0 ? 0 : value; c.drop_graphs(); }   // baked into captured launch sequences
-        else if (s == "p_wt") { c.p_wt = value != 0; c.drop_graphs(); }
-        else if (s == "real_il_reference") c.real_il_reference = value > 0;
-        else if (s == "graph") c.use_graph = value > 0;
-        else if (s == "overlap") c.overlap = value < 0 ? eig::kOverlapDefault : (value & 3);
-        else if (s == "trsm_base") c.trsm_base = value <= 0 ? eig::kTrsmBaseDefault : eig::norm_trsm_base(value);
-        else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
-        else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? eig::kGstModeDefault : value;
-        else if (s == "gst_thr") c.gst_thr = value <= 0 ? eig::kGstThrDefault : (value < 256 ? 256 : value);
-        else if (s == "trd_fuse") { c.trd_fuse = value < 0 ? -1 : (value > 8192 ? 8192 : value); c.drop_graphs(); }
-        else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;
-        else if (s == "batch_fuse") c.batch_fuse = (value < 1 || value > 4) ? -1 : value;
-        else if (s == "tridiag") c.tridiag_device = value < 0 ? eig::kTridiagDefault : (value > 0 ? 1 : 0);
-        else return -1;
-        return 0;
+        return eig::apply_option(eig::ctx(), std::string(name ? name : ""), value) ? 0 : -1;
     } catch (...) {
         return -1;
     }

@@ -7,6 +7,7 @@
 #include <functional>
 #include <initializer_list>
 
+#include <climits>
 #include "../../include/eigsolve_gpu.h"
 #include "stedc.h"
 #include "trd.h"
@@ -291,7 +292,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         (void)hemv_scratch_touch<T>(c, N, cur + 5);   // all scratch used inside the captured region exists before capture
         cur[0] = Aw; cur[1] = Ww; cur[2] = tauw; cur[3] = dw; cur[4] = ew;
         char key[64];
-        snprintf(key, sizeof key, "trd_%c_%d_%d_%d_%d%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks, c.p_wt, c.hemv_balance);
+        snprintf(key, sizeof key, "trd_%c_%d_%d_%d_%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks, c.trd_finish);   // every option the captured launch sequence bakes in
         Ctx::GraphEntry& ge = c.graphs[key];
         bool valid = ge.exec != nullptr;
         for (int q = 0; q < 16 && valid; ++q) valid = (ge.ptrs[q] == cur[q]);
@@ -446,16 +447,19 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
         pt.end(PH_GST);
     }
     int info;
+    // The eigenvectors of the standard problem are formed in library scratch (N x m) and the final solve writes Z = U^-1 Zs
+    // out of place: no staging copies inside the solve (blas3.hip, trsm_LUN), and the caller's Z is written exactly once.
+    T* Zs = c.scratch<T>(Tr<T>::cx ? "evd_Zsz" : "evd_Zsd", (size_t)N * m);
     {
         PhaseRange r(Tr<T>::cx ? "zheevd_gpu" : "dsyevd_gpu");   // :161
-        info = heevd_core<T>(c, il, iu, N, A, lda, Z, ldz, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork, lswork, iwork,
+        info = heevd_core<T>(c, il, iu, N, A, lda, Zs, N, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork, lswork, iwork,
                              liwork);  // :163
     }
     if (info != 0) return -1;
     {
         PhaseRange r(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167
         pt.begin(PH_TRSM);
-        trsm_LUN<T>(c, st, N, m, B, ldb, 0, Z, ldz, c.trsm_base);  // :169
+        trsm_LUN<T>(c, st, N, m, B, ldb, 0, Zs, N, Z, ldz, c.trsm_base);  // :169  Z = U^-1 Zs
         pt.end(PH_TRSM);
     }
     pt.begin(PH_D2H);
@@ -541,18 +545,19 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
             }
         }
         size_t tot = (size_t)N * m;
+        T* Zs = c.scratch<T>(Tr<T>::cx ? "evd_Zsz" : "evd_Zsd", (size_t)N * m);   // as in hegvdx_core
         hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m,
-                           (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Z[q], ldz);
+                           (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Zs, N);
         EIG_HIP(hipMemcpyAsync(w_h[q], w_d[q], sizeof(double) * N, hipMemcpyDeviceToHost, st));
         {
             PhaseRange r(Tr<T>::cx ? "zunmtr" : "dormtr");
             bt_build_T<T>(c, st, N, A[q], lda, tau_d[q], c.bt_nb);
-            bt_apply<T>(c, st, N, m, A[q], lda, Z[q], ldz, c.bt_nb);
+            bt_apply<T>(c, st, N, m, A[q], lda, Zs, N, c.bt_nb);
         }
         // the inverse diagonal blocks in the context's scratch are those of the LAST factorization: rebuild problem q's
         build_invU<T>(c, st, N, (const T*)B[q], ldb);
         build_inv_blocks<T>(c, st, N, (const T*)B[q], ldb);
-        trsm_LUN<T>(c, st, N, m, B[q], ldb, 0, Z[q], ldz, c.trsm_base);
+        trsm_LUN<T>(c, st, N, m, B[q], ldb, 0, Zs, N, Z[q], ldz, c.trsm_base);
         if (!skip_host_copy) {
             hipError_t e = hipMemcpy2DAsync(Z_h[q], sizeof(T) * ldz_h, Z[q], sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
             if (e != hipSuccess) {
@@ -615,8 +620,26 @@ static int hegvdx_batch_workers(Ctx& c0, int nprob, int N, T* const* A, int lda,
         if (infos[q] == -2) infos[q] = -1;
         bad |= (infos[q] != 0);
     }
+    // (the caller's thread is one of the workers: its context holds the phase times of the last problem it solved itself --
+    //  a batch call reports the total only)
+    clear_phases(c0);
     c0.phase_ms[PH_TOTAL] = now_ms() - t_all;
     return bad ? -1 : 0;
+}
+
+// info[] of a batch call: pre-filled with a sentinel, so that whatever path rejects or aborts the call (argument checks, a HIP
+// failure before the first synchronisation), every entry that was not explicitly reported reads -1 afterwards
+// (include/eigsolve_gpu.h: "a rejected batch call returns -1 and every info[q] = -1").
+constexpr int kInfoUnset = INT_MIN;
+static void batch_info_begin(int nprob, int* info) {
+    if (info && nprob >= 1 && nprob <= 64)
+        for (int q = 0; q < nprob; ++q) info[q] = kInfoUnset;
+}
+static int batch_info_end(int rc, int nprob, int* info) {
+    if (info && nprob >= 1 && nprob <= 64)
+        for (int q = 0; q < nprob; ++q)
+            if (info[q] == kInfoUnset) info[q] = rc == 0 ? 0 : -1;
+    return rc;
 }
 
 // the batch ABI hands over arrays of pointers: none of them, and none of their entries, may be null
@@ -722,6 +745,7 @@ int eigsolve_dsygvdx(int N, double* A_d, int lda, double* B_d, int ldb, double* 
 int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* const* B_d, int ldb, void* const* Z_d, int ldz, int il,
                            int iu, double* const* w_d, void* const* work_d, int lwork, double* const* rwork_d, int lrwork,
                            void* const* Z_h, int ldz_h, double* const* w_h, int* info, int skip_host_copy) {
+    batch_info_begin(nprob, info);
     int rc = guarded(nullptr, [&]() -> int {
         const long n = N;
         if (nprob < 1 || nprob > 64 || !info) { printf(" zhegvdx_gpu batch error: nprob must be in 1..64 and info an array of nprob ints\n"); return -1; }
@@ -732,7 +756,6 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
                                    (const void* const*)work_d, (const void* const*)rwork_d, (const void* const*)w_h}) ||
             (!skip_host_copy && !batch_ptrs_ok(nprob, {(const void* const*)Z_h}))) {
             printf(" zhegvdx_gpu batch error: null pointer in the argument arrays\n");
-            for (int q = 0; q < nprob; ++q) info[q] = -1;
             return -1;
         }
         Ctx& c = ctx();
@@ -749,13 +772,14 @@ int eigsolve_zhegvdx_batch(int nprob, int N, void* const* A_d, int lda, void* co
         return hegvdx_batch_core<cplx>(c, nprob, N, A.data(), lda, B.data(), ldb, Z.data(), ldz, il, iu, w_d, e.data(), tau.data(),
                                        W.data(), w_h, Zh.data(), ldz_h, skip_host_copy, info, "zhegvdx_gpu");
     });
-    return rc;
+    return batch_info_end(rc, nprob, info);
 }
 
 int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double* const* B_d, int ldb, double* const* Z_d, int ldz, int il,
                            int iu, double* const* w_d, double* const* work_d, int lwork, double* const* Z_h, int ldz_h,
                            double* const* w_h, int* info, int skip_host_copy) {
-    return guarded(nullptr, [&]() -> int {
+    batch_info_begin(nprob, info);
+    const int rc = guarded(nullptr, [&]() -> int {
         const long n = N;
         if (nprob < 1 || nprob > 64 || !info) { printf(" dsygvdx_gpu batch error: nprob must be in 1..64 and info an array of nprob ints\n"); return -1; }
         if (lwork < 2 * 64 * 64 + 66 * n) { printf(" dsygvdx_gpu error: lwork must be at least 2*64*64 + 66*N\n"); return -1; }
@@ -764,7 +788,6 @@ int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double
                                    (const void* const*)work_d, (const void* const*)w_h}) ||
             (!skip_host_copy && !batch_ptrs_ok(nprob, {(const void* const*)Z_h}))) {
             printf(" dsygvdx_gpu batch error: null pointer in the argument arrays\n");
-            for (int q = 0; q < nprob; ++q) info[q] = -1;
             return -1;
         }
         Ctx& c = ctx();
@@ -777,6 +800,7 @@ int eigsolve_dsygvdx_batch(int nprob, int N, double* const* A_d, int lda, double
         return hegvdx_batch_core<double>(c, nprob, N, A_d, lda, B_d, ldb, Z_d, ldz, il, iu, w_d, e.data(), tau.data(), W.data(), w_h, Z_h,
                                          ldz_h, skip_host_copy, info, "dsygvdx_gpu");
     });
+    return batch_info_end(rc, nprob, info);
 }
 
 int eigsolve_zheevd(int il, int iu, int N, void* A_d, int lda, void* Z_d, int ldz, double* w_d, void* work_d, int lwork,
@@ -994,7 +1018,9 @@ template <class T> static int trsm_entry(int N, int m, const T* U, int ldu, T* Z
         Ctx& c = ctx();
         build_invU<T>(c, c.s1, N, U, ldu);
         build_inv_blocks<T>(c, c.s1, N, U, ldu);
-        trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Z, ldz, c.trsm_base);
+        T* Xs = c.scratch<T>(Tr<T>::cx ? "evd_Zsz" : "evd_Zsd", (size_t)N * m);     // the solve is out of place: X = copy of Z
+        EIG_HIP(hipMemcpy2DAsync(Xs, sizeof(T) * N, Z, sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToDevice, c.s1));
+        trsm_LUN<T>(c, c.s1, N, m, U, ldu, 0, Xs, N, Z, ldz, c.trsm_base);
         c.sync(c.s1);
         return 0;
     });

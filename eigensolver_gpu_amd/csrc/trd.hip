@@ -34,12 +34,10 @@ namespace eig {
 #endif
 #if EIG_TRD_TIMING
 __device__ unsigned long long g_trd_stamp[4][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
-__device__ unsigned long long g_trd_count[4];       // kernel 2 / 3: panel_col_kernel, an owner tile (block 0) / an off-diagonal tile (block 1)
-#define CSTAMP(PH) do { if (blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_trd_stamp[2 + blockIdx.x][PH], (unsigned long long)(__builtin_readcyclecounter() - CT0)); } while (0)
+__device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel, 1: panel_row_kernel
 #define TSTAMP(KID, PH, T0) do { if (blockIdx.x == (KID == 0 ? gg : 0) && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
 #else
 #define TSTAMP(KID, PH, T0) do { } while (0)
-#define CSTAMP(PH) do { } while (0)
 #endif
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
@@ -60,26 +58,7 @@ template <class T> struct PanelArgs {
     int nblkA;         // norm partials (one per row-kernel wave) produced for column i
     int gh;            // hemv workgroups used for the column being finished / generated
     int nchunk;        // gemv row chunks for that column
-    int wt;            // 1: the hemv partials are stored write-through (sc1), see store_partial
 };
-
-// The hemv partials P (up to nt*n*s bytes = 4 MB at n = 4096) are the only sizeable data the mat-vec kernel writes, and
-// the next kernel (on other XCDs) reads all of it.  A plain store leaves the lines dirty in this XCD's L2 and the kernel
-// boundary pays for their write-back (MI355X_MICROARCH.md, row "boundary": + B / 6 TB/s); an sc1 store writes through
-// while the kernel is still streaming.
-__device__ __forceinline__ void store_partial(cplx* p, cplx v, int wt) {
-    if (wt) {
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 t = {v.x, v.y};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-    } else {
-        *p = v;
-    }
-}
-__device__ __forceinline__ void store_partial(double* p, double v, int wt) {
-    if (wt) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-    else *p = v;
-}
 
 // A launch serves NB independent problems of the same order in lockstep (blockIdx.y = problem): the per-column kernels of
 // a tridiagonalization are latency-bound for most of the reduction (4.3-4.8 us per mat-vec launch up to
@@ -529,12 +508,12 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
         if (diag) {
             T s = yv + tv;
-            store_partial(&a.P[(size_t)Jc * a.ldp + r0 + lane], s, a.wt);
+            a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
             fmac_(Sacc, vI, s);
             if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
         } else {
-            store_partial(&a.P[(size_t)Jc * a.ldp + r0 + lane], yv, a.wt);
-            store_partial(&a.P[(size_t)Ic * a.ldp + c0 + lane], tv, a.wt);
+            a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
+            a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
             fmac_(Sacc, vI, yv);
             fmac_(Sacc, vJ, tv);
         }
@@ -545,398 +524,6 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     TSTAMP(0, 5, T0);
 }
 
-// ------------------------------------------------------------------------------------------
-// panel_col_kernel : ONE launch per column for the tail of the reduction (order <= "trd_fuse_n").
-//
-// Up to n ~ 1300 (complex) a column's two kernels cost 4.3-5 us each whatever the work: launch ramp, one dependent memory
-// round trip, a kernel boundary.  Here the row work of panel_row_kernel is folded into the mat-vec launch: a workgroup owns
-// one 64x64 tile (I, J) of the upper triangle and FIRST derives, redundantly, the 2 x 64 entries x_I, x_J of the updated
-// column it is about to multiply with (finishing W(:, c) for those rows on the way) from data of the previous launch --
-// O((2 npo + nt) x 128) values from L2 -- while its tile is already in flight from HBM.  Diagonal tiles are the OWNERS of
-// their 64 rows: only they store W(:, c), the finished reflector v_c, the raw new column and the per-block partial sums.
-//
-// What makes one launch per column possible is linearity: v = scale * xh + e_(n-1) (xh = raw column, last entry zeroed).
-// scale needs ||xh|| -- a reduction over ALL rows, i.e. over all workgroups of the launch that produces xh -- so a launch
-// never applies its own column's scalars: it multiplies the tile with the RAW xh and publishes raw partials
-//     P^  = A xh (per tile stripe),  S^ = xh^H A xh,  D^ = xh^H A(:, n-1),  Z^ = [V W]^H xh (per owner block),  ||xh||^2,
-// and the NEXT launch, which can sum the norm partials, reconstructs
-//     y = scale P^ + A(:, n-1),   z = scale Z^ + [V W](n-1, :)^H,   v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
-// before it finishes W(:, c) = tau (y - V z2' - W z1') + alpha v_c exactly as panel_row_kernel does (zhetrd_gpu.F90:335-511,
-// :750-879).  Partial-sum buffers are double (a launch reads the previous column's set and writes its own).
-//   FIRST   : first column of a panel -- nothing to finish, x = A(:, i) as the trailing update left it;
-//   FINONLY : after the last column of a panel -- only the owners run: W(:, c), v_c, e, tau; no new column, no mat-vec.
-// ------------------------------------------------------------------------------------------
-template <class T> struct ColArgs {
-    T* A; int lda;
-    T* W; int ldw;
-    int np, nb, i;           // i = column generated by this launch (c = i + 1 is finished by it); FINONLY: i = c - 1
-    double* d; double* e; T* tau;
-    // set of the previous launch (describes column c) / set written by this launch (describes column i)
-    const T* xprev; T* xnew;
-    const T* Pp; T* Pn; int ldp;
-    const T* Sp; T* Sn;
-    const T* Dp; T* Dn;
-    const double* NPp; double* NPn;
-    const T* Zpp; T* Zpn;
-    const T* alphap; T* alphan;
-};
-template <class T, int NB> struct ColBatch {
-    ColArgs<T> p[NB];
-};
-
-constexpr int CTH = 320;    // panel_col_kernel: four row / tile waves + one scalar wave
-constexpr int ZG = 17;      // Z^ partial blocks per lane without the tail loop (2 halves x 17 >= 33 blocks: order <= 2111)
-
-template <class T, int NB, bool FIRST, bool FINONLY>
-__global__ void __launch_bounds__(CTH) panel_col_kernel(ColBatch<T, NB> ab) {
-    const ColArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
-#if EIG_TRD_TIMING
-    const long long CT0 = __builtin_readcyclecounter();
-    if (!FIRST && !FINONLY && blockIdx.x < 2 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_trd_count[2 + blockIdx.x], 1ULL);
-#endif
-    const int i = a.i, c = i + 1;
-    const int n = i;                                   // order of the mat-vec: v_i has rows 0 .. i-1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const T zero = Tr<T>::zero();
-    int I, J;
-    if (FINONLY) { I = J = (int)blockIdx.x; }
-    else tile_decode((int)blockIdx.x, I, J);
-    const bool owner = (I == J);
-    const int r0 = I * HT, c0 = J * HT;
-    const int wbase = a.np - a.nb;
-    const int npo = FIRST ? 0 : a.np - 1 - c;          // panel columns older than c
-    const int ntc = c / HT + 1;                        // 64-row blocks of the previous launch (rows 0 .. c)
-    const int nz = n - 1;                              // xh: rows >= nz are zero
-
-    __shared__ T zs[2][2][NBMAX];                      // [which][half][kk] gathered partial sums of Z^ (raw)
-    __shared__ T rowW[NBMAX + 1], rowV[NBMAX + 1];     // conj of row i of W / V (older columns), [npo] = column c itself
-    __shared__ T s4[4];
-    __shared__ T part[2][4][3][HT];                    // [block sel][sub][psum / Q1 / Q2][row]
-    __shared__ T xs[2][HT];                            // raw new column: rows of block I / block J
-    __shared__ T scal[4];                              // scale, tau, alpha (scalar wave -> everybody)
-    __shared__ T redy[4][HT], redt[HT];
-    __shared__ T vcs[HT], wcs[HT];                     // v_c, w_c of the owner's rows (for the Z^ partials)
-
-    // row-work roles of waves 0-3.  Off-diagonal tile: waves 0,1 -> rows of block I, waves 2,3 -> rows of block J, the two
-    // waves of a block split the panel columns / stripes by parity; diagonal tile (and FINONLY): all four on block I.
-    const int bsel = owner ? 0 : ((wave >> 1) & 1);
-    const int nsub = owner ? 4 : 2;
-    const int sub = owner ? (wave & 3) : (wave & 1);
-    const int rb0 = (bsel == 0) ? r0 : c0;
-    const int r = rb0 + lane;
-    const int rows = i + 1;                            // rows 0 .. i of the panel are live
-    const bool active = r < rows;
-    const size_t rc = (size_t)min(r, rows - 1);
-
-    // =========================== the scalar wave ===========================
-    // larfg scalars of column c, z totals, alpha, w_i: a serial chain (~2500 cycles) that runs beside the row work
-    if (wave == 4) {
-        if constexpr (!FIRST) {
-            T l_ww = zero, l_wv = zero;
-            if (lane < npo) {
-                const int k = c + 1 + lane;
-                l_ww = a.W[(size_t)i + (size_t)(k - wbase) * a.ldw];
-                l_wv = a.A[(size_t)i + (size_t)k * a.lda];
-            }
-            const int ql = min(lane, ntc - 1);
-            T l_p = a.Pp[(size_t)ql * a.ldp + i];
-            double npv = a.NPp[ql];
-            T dv = a.Dp[ql];
-            const T alpha_e = *a.alphap;
-            const double aLL = real_(a.A[(size_t)i + (size_t)i * a.lda]);
-            l_p = sel(lane < ntc, l_p, zero); npv = lane < ntc ? npv : 0.0; dv = sel(lane < ntc, dv, zero);
-            for (int q = lane + 64; q < ntc; q += 64) { l_p = l_p + a.Pp[(size_t)q * a.ldp + i]; npv += a.NPp[q]; dv = dv + a.Dp[q]; }
-            if (lane < npo) { rowW[lane] = conj_(l_ww); rowV[lane] = conj_(l_wv); }
-            __syncthreads();                           // #1: Z^ halves and S^ partials are in LDS, rowW / rowV published
-            const double ss = wave_sum(npv);
-            double beta;
-            T tau, scale;
-            larfg_scalars<T>(ss, alpha_e, beta, tau, scale);
-            if (blockIdx.x == 0 && lane == 0) { a.e[c - 1] = beta; a.tau[c - 1] = tau; }
-            const T Dsum = wave_sum(dv);
-            const T Sraw = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-            T cs = zero;
-            fmac_(cs, scale, Dsum);
-            // v^H A v = |scale|^2 S^ + 2 Re(conj(scale) D^) + A(n-1, n-1)
-            const double S = abs2_(scale) * real_(Sraw) + 2.0 * real_(cs) + aLL;
-            T z1l = zero, z2l = zero;
-            if (lane < npo) {
-                z1l = scale * (zs[0][0][lane] + zs[0][1][lane]) + conj_(l_wv);
-                z2l = scale * (zs[1][0][lane] + zs[1][1][lane]) + conj_(l_ww);
-            }
-            T t = zero;
-            fmac_(t, z1l, z2l);
-            const double zz = wave_sum(real_(t));
-            const T alpha = Tr<T>::make((-0.5 * abs2_(tau)) * (S - 2.0 * zz), 0.0);   // (v^H A v is real for Hermitian A)
-            // w_i = W(i, c): row i of the column being finished;  y_i = scale P^(i) + A(i, i),  v_c(i) = 1
-            const T yi = scale * wave_sum(l_p) + Tr<T>::make(aLL, 0.0);
-            const T u = wave_sum(sel(lane == 0, yi, zero) - (l_ww * z1l + l_wv * z2l));
-            const T wi = tau * u + alpha;
-            if (lane == 0) { rowW[npo] = conj_(wi); rowV[npo] = Tr<T>::one(); scal[0] = scale; scal[1] = tau; scal[2] = alpha; }
-        } else {
-            __syncthreads();                           // #1
-        }
-        __syncthreads();                               // #2: scalars published, row-work partial sums published
-        if constexpr (FINONLY) return;
-        __syncthreads();                               // #3: xs published
-        __syncthreads();                               // #4: tile partial sums published
-        // finish the tile: raw partials of the new column
-        const T yv = (redy[0][lane] + redy[1][lane]) + (redy[2][lane] + redy[3][lane]);
-        const T tv = redt[lane];
-        const T xI = sel(r0 + lane < nz, xs[0][lane], zero);
-        const T xJ = sel(c0 + lane < nz, xs[1][lane], zero);
-        T Sacc = zero;
-        if (owner) {
-            const T sm = yv + tv;
-            a.Pn[(size_t)J * a.ldp + r0 + lane] = sm;
-            fmac_(Sacc, xI, sm);
-        } else {
-            a.Pn[(size_t)J * a.ldp + r0 + lane] = yv;
-            a.Pn[(size_t)I * a.ldp + c0 + lane] = tv;
-            fmac_(Sacc, xI, yv);
-            fmac_(Sacc, xJ, tv);
-        }
-        Sacc = wave_sum(Sacc);
-        if (lane == 0) a.Sn[blockIdx.x] = Sacc;
-        if (!FIRST) CSTAMP(6);
-        return;
-    }
-
-    // =========================== waves 0-3 ===========================
-    // ---- every load that depends on nothing: the tile, the gather of Z^ / S^, the first row-work loads ----
-    T av[16];
-    if constexpr (!FINONLY) {
-        const size_t roff = (size_t)min(r0 + lane, max(n - 1, 0));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, max(n - 1, 0)) * a.lda];
-    }
-    T xr_new = zero, wr = zero, vr = zero;
-    if constexpr (FIRST) {
-        T acur = a.A[rc + (size_t)i * a.lda];
-        if (r == i) acur = Tr<T>::realpart(acur);
-        xr_new = sel(active, acur, zero);
-        __syncthreads();                               // #1
-        __syncthreads();                               // #2
-    } else {
-        {
-            // gather: Z^ (lane = panel column, waves = which x half of the blocks), S^ (all threads of waves 0-3)
-            const int which = wave & 1, half = wave >> 1;
-            const int kz = min(lane, max(npo - 1, 0));
-            T zt[ZG];
-#pragma unroll
-            for (int u = 0; u < ZG; ++u) zt[u] = a.Zpp[(size_t)(min(half + 2 * u, ntc - 1) * 2 + which) * NBMAX + kz];
-            const int ntl = ntc * (ntc + 1) / 2;
-            T st[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) st[u] = a.Sp[min(tid + 256 * u, ntl - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-            T zsum = zero, Ssum = zero;
-#pragma unroll
-            for (int u = 0; u < ZG; ++u) zsum = zsum + sel(half + 2 * u < ntc, zt[u], zero);
-            for (int q = half + 2 * ZG; q < ntc; q += 2) zsum = zsum + a.Zpp[(size_t)(q * 2 + which) * NBMAX + kz];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) Ssum = Ssum + sel(tid + 256 * u < ntl, st[u], zero);
-            for (int q = tid + 768; q < ntl; q += 256) Ssum = Ssum + a.Sp[q];
-            if (lane < npo) zs[which][half][lane] = zsum;
-            Ssum = wave_sum(Ssum);
-            if (lane == 0) s4[wave] = Ssum;
-        }
-        if (!FINONLY) CSTAMP(0);
-        __syncthreads();                               // #1
-        if (!FINONLY) CSTAMP(1);
-        // ---- row sums that need no scalar:  psum = sum of P^ stripes,  Q1 = sum W z1^ + V z2^,  Q2 = sum V conj(W(i,:)) + W conj(V(i,:))
-        //      (y = scale psum + A(:, i);  w = tau (y - scale Q1 - Q2) + alpha v_c;  column update = Q2 + v_c conj(w_i) + w) ----
-        constexpr int KB = Tr<T>::cx ? 4 : 8;          // panel columns per load batch (two batches in flight)
-        T psum = zero, q1 = zero, q2 = zero;
-        {
-            T pt[ZG];
-#pragma unroll
-            for (int u = 0; u < ZG; ++u) {
-                const int q = sub + nsub * u;
-                pt[u] = (u * nsub < 2 * ZG) ? a.Pp[(size_t)min(q, ntc - 1) * a.ldp + rc] : zero;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < ZG; ++u) psum = psum + sel(sub + nsub * u < ntc && u * nsub < 2 * ZG, pt[u], zero);
-            for (int q = sub + nsub * ZG; q < ntc; q += nsub) psum = psum + a.Pp[(size_t)q * a.ldp + rc];
-        }
-        {
-            T vb[2][KB], wb[2][KB];
-            const int nmine = (npo - sub + nsub - 1) / nsub;       // my panel columns: kk = sub + nsub * m
-            auto issue = [&](int buf, int m0) {
-#pragma unroll
-                for (int m = 0; m < KB; ++m) {
-                    const int kk = min(sub + nsub * (m0 + m), max(npo - 1, 0));
-                    const int k = c + 1 + kk;
-                    vb[buf][m] = a.A[rc + (size_t)k * a.lda];
-                    wb[buf][m] = a.W[rc + (size_t)(k - wbase) * a.ldw];
-                }
-            };
-            auto consume = [&](int buf, int m0) {
-#pragma unroll
-                for (int m = 0; m < KB; ++m) {
-                    const int kk = sub + nsub * (m0 + m);
-                    if (m0 + m < nmine) {
-                        const T z1r = zs[0][0][kk] + zs[0][1][kk], z2r = zs[1][0][kk] + zs[1][1][kk];
-                        q1 = q1 + (wb[buf][m] * z1r + vb[buf][m] * z2r);
-                        q2 = q2 + (vb[buf][m] * rowW[kk] + wb[buf][m] * rowV[kk]);
-                    }
-                }
-            };
-            if (nmine > 0) issue(0, 0);
-            for (int m0 = 0; m0 < nmine; m0 += 2 * KB) {
-                if (m0 + KB < nmine) issue(1, m0 + KB);
-                consume(0, m0);
-                if (m0 + 2 * KB < nmine) issue(0, m0 + 2 * KB);
-                if (m0 + KB < nmine) consume(1, m0 + KB);
-            }
-        }
-        part[bsel][sub][0][lane] = psum;
-        part[bsel][sub][1][lane] = q1;
-        part[bsel][sub][2][lane] = q2;
-        const T xc_raw = a.xprev[rc];
-        T acur = a.A[rc + (size_t)i * a.lda];          // column i: A(r, n_c - 1) for y AND the column to update
-        if (r == i) acur = Tr<T>::realpart(acur);
-        __syncthreads();                               // #2
-        if (!FINONLY) CSTAMP(3);
-        const T scale = scal[0], tau = scal[1], alpha = scal[2];
-        T ps = part[bsel][0][0][lane] + part[bsel][1][0][lane];
-        T a1 = part[bsel][0][1][lane] + part[bsel][1][1][lane];
-        T a2 = part[bsel][0][2][lane] + part[bsel][1][2][lane];
-        if (owner) {
-            ps = ps + (part[0][2][0][lane] + part[0][3][0][lane]);
-            a1 = a1 + (part[0][2][1][lane] + part[0][3][1][lane]);
-            a2 = a2 + (part[0][2][2][lane] + part[0][3][2][lane]);
-        }
-        vr = (r < c - 1) ? scale * xc_raw : ((r == c - 1) ? Tr<T>::one() : zero);
-        const T y = scale * ps + acur;
-        wr = tau * (y - scale * a1 - a2) + alpha * vr;
-        if constexpr (!FINONLY) {
-            const T upd = a2 + (vr * rowW[npo] + wr * rowV[npo]);
-            T anew = acur - upd;
-            if (r == i) anew = Tr<T>::realpart(anew);
-            xr_new = sel(active, anew, zero);
-        }
-        if (owner && wave == 0 && active) {            // owners publish the finished column c
-            a.W[(size_t)r + (size_t)(c - wbase) * a.ldw] = wr;
-            a.A[(size_t)r + (size_t)c * a.lda] = vr;
-        }
-    }
-    if constexpr (FINONLY) return;
-
-    // ---------------- publish the raw new column (LDS for this tile, global by the owners) ----------------
-    if (owner) {
-        if (wave == 0) { xs[0][lane] = xr_new; xs[1][lane] = xr_new; vcs[lane] = vr; wcs[lane] = wr; }
-    } else if ((wave & 1) == 0) {
-        xs[bsel][lane] = xr_new;
-    }
-    if (owner && wave == 0) {
-        if (active) {
-            a.xnew[r] = xr_new;
-            if (r == i - 1) *a.alphan = xr_new;
-            if (r == i) a.d[i] = real_(xr_new);        // (A(i,i) itself stays as it is: every workgroup of this launch reads it)
-        }
-        const T alast = a.A[(size_t)min(r, max(n - 1, 0)) + (size_t)max(n - 1, 0) * a.lda];   // A(r, n-1), used for r < nz
-        double nrm = (active && r <= i - 2) ? abs2_(xr_new) : 0.0;
-        T dd = zero;
-        if (active && r < nz) fmac_(dd, xr_new, alast);
-        nrm = wave_sum(nrm);
-        dd = wave_sum(dd);
-        if (lane == 0) { a.NPn[I] = nrm; a.Dn[I] = dd; }
-    }
-    __syncthreads();                                   // #3
-    if (!FIRST) CSTAMP(4);
-
-    // ---------------- the tile: y_I += A_IJ xh_J,  y_J += A_IJ^H xh_I  (as panel_mv_kernel, raw xh) ----------------
-    {
-        const bool diag = owner;
-        const int rr = r0 + lane;
-        const T xr = sel(rr < nz, xs[0][lane], zero);
-        const bool interior = !diag && r0 + HT <= n && c0 + HT <= n && c0 + HT <= nz;
-        T yI = zero;
-        auto half = [&](int jb, T& w0, T& w1) {
-            T tj[8];
-            if (interior) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    fma_(yI, av[jb + j], xs[1][wave * 16 + jb + j]);
-                    T p = zero;
-                    fmac_(p, av[jb + j], xr);
-                    tj[j] = p;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int cc = c0 + wave * 16 + jb + j;
-                    const bool ok = (rr < n) && (cc < n) && (!diag || rr <= cc);
-                    const bool dg = diag && rr == cc;
-                    T v = sel(ok, av[jb + j], zero);
-                    v = sel(dg, Tr<T>::realpart(v), v);
-                    fma_(yI, v, sel(cc < nz, xs[1][wave * 16 + jb + j], zero));
-                    T p = zero;
-                    fmac_(p, sel(dg, zero, v), xr);
-                    tj[j] = p;
-                }
-            }
-            transpose_reduce8_phase1<T>(tj, w0, w1);
-        };
-        T wa0, wa1, wb0, wb1;
-        half(0, wa0, wa1);
-        half(8, wb0, wb1);
-        const T tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
-        redy[wave][lane] = yI;
-        if ((lane & 3) == 0) redt[wave * 16 + transpose_col_of_lane(lane)] = tval;
-    }
-    __syncthreads();                                   // #4 (the scalar wave finishes the tile)
-    if (!FIRST) CSTAMP(5);
-    // ---------------- owners: Z^ partials of the new column over their 64 rows ([V W]^H xh for the columns older than i) ----
-    if (owner) {
-        const int npn = a.np - 1 - i;                  // panel columns older than i: k = c + kk, kk = 0 .. npn-1
-        const int rr = r0 + lane;
-        const T xh = sel(rr < nz, xs[0][lane], zero);
-        const size_t rcl = (size_t)min(rr, max(n - 1, 0));
-        const int nitem = 2 * npn;                     // items: [V columns kk = 0 .. npn-1 | W columns]; 16 per wave and pass
-        for (int g0 = wave * 16; g0 < nitem; g0 += 64) {
-            T src[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int it = min(g0 + j, nitem - 1);
-                const bool isw = it >= npn;
-                const int kk = isw ? it - npn : it;
-                const T* base = isw ? a.W + (size_t)(c + kk - wbase) * a.ldw : a.A + (size_t)(c + kk) * a.lda;
-                src[j] = base[rcl];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            T wv[2][2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                T tj[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int it = g0 + 8 * h + j;
-                    T sv = src[8 * h + j];
-                    if (it == 0) sv = vcs[lane];                 // column c itself: just finished by this workgroup
-                    if (it == npn) sv = wcs[lane];
-                    T p = zero;
-                    fmac_(p, sel(rr < n && it < nitem, sv, zero), xh);
-                    tj[j] = p;
-                }
-                transpose_reduce8_phase1<T>(tj, wv[h][0], wv[h][1]);
-            }
-            const T tval = transpose_reduce_phase2<T>(wv[0][0], wv[0][1], wv[1][0], wv[1][1], lane);
-            if ((lane & 3) == 0) {
-                const int it = g0 + transpose_col_of_lane(lane);
-                if (it < nitem) {
-                    const bool isw = it >= npn;
-                    a.Zpn[(size_t)(I * 2 + (isw ? 1 : 0)) * NBMAX + (isw ? it - npn : it)] = tval;
-                }
-            }
-        }
-    }
-    if (!FIRST) CSTAMP(7);
-}
-
-// y = sum of the hemv partials (stand-alone hemv entry point only)
 template <class T> __global__ void __launch_bounds__(256) hemv_gather_kernel(int n, int nt, const T* P, int ldp, T* y) {
     int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
@@ -1028,6 +615,169 @@ template <class T> __global__ void __launch_bounds__(256) hetd2_kernel(int n, T*
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// hetd2_wide_kernel: the END of the reduction in ONE workgroup, matrix resident in REGISTERS.
+//
+// The reference hands only the last 32 columns to a one-block kernel (zhetrd_gpu.F90:84-87, zhetd2_gpu.F90:3-203); every
+// column above that costs two chip-wide dependent launches here (~9 us) however small the trailing matrix is.  A CU has
+// 512 KB of vector registers (and 160 KB of LDS): the full Hermitian matrix of order 128 (complex) / 192 (real) fits in the
+// registers of 512 threads.  Thread (tr, tc) of a 16 x 32 grid owns the entries H(tr + 16 p, tc + 32 q) -- a cyclic layout, so
+// the work per column shrinks with the trailing order for every thread alike; BOTH triangles are kept and updated (the
+// rank-2 update is symmetric), so y = H v needs no transposed products: a thread multiplies its rows with its columns
+// of v and the 32 threads of a half wave (fixed tr, all tc) sum with DPP / permlane16 moves.  Column j, right to left, is
+// LAPACK's zhetd2 'U' step: x = H(0:j-1, j) -> larfg -> y = tau H v -> w = y - 1/2 tau (y^H v) v -> H -= v w^H + w v^H.
+// Two workgroup barriers per column: x published (every wave then derives the larfg scalars redundantly, as the panel
+// kernels do), y published (every wave derives alpha and its w entries).  Vectors go through double-buffered LDS lines.
+// Outputs as zhetd2_gpu: d, e, tau, reflectors in the upper triangle; the superdiagonal holds e inside the reference's final
+// 32x32 block and the explicit 1 of the blocked part above it (zhetrd_gpu.F90:92), i.e. exactly the reference's layout.
+// ------------------------------------------------------------------------------------------
+constexpr int WTR = 16, WTC = 32;   // thread grid of hetd2_wide_kernel
+// sum over the 32 lanes of each half wave, result in every lane of the half
+__device__ __forceinline__ double half_sum32(double v) {
+    v = row_sum16(v);
+    double t = v;
+    swap_rows(v, t);      // v = {r0, r0, r2, r2}, t = {r1, r1, r3, r3}
+    return v + t;
+}
+__device__ __forceinline__ cplx half_sum32(cplx v) { return cplx{half_sum32(v.x), half_sum32(v.y)}; }
+
+template <class T, int PC>
+__global__ void __launch_bounds__(WTR * WTC) hetd2_wide_kernel(int n, T* A, int lda, double* d, double* e, T* tau) {
+    constexpr int PR = 2 * PC, NMAX = WTC * PC;
+    static_assert(WTR * PR == NMAX, "square matrix");
+    __shared__ T xs[2][NMAX], ys[2][NMAX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tr = tid >> 5, tc = tid & 31;
+    const T zero = Tr<T>::zero();
+
+    T a[PR][PC];
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+#pragma unroll
+        for (int q = 0; q < PC; ++q) {
+            const int r = tr + WTR * p, cc = tc + WTC * q;
+            const bool in = r < n && cc < n;
+            const int rl = min(r, n - 1), cl = min(cc, n - 1);
+            const T v = A[(size_t)min(rl, cl) + (size_t)max(rl, cl) * lda];      // stored upper triangle
+            T h = sel(r <= cc, v, conj_(v));
+            h = sel(r == cc, Tr<T>::realpart(h), h);
+            a[p][q] = sel(in, h, zero);
+        }
+
+    for (int j = n - 1; j >= 1; --j) {
+        const int buf = j & 1;
+        const int qj = j >> 5, tcj = j & 31;
+        const int kp = (j + WTR - 1) / WTR, kq = (j + WTC - 1) / WTC;   // register rows / columns that still hold rows, columns < j
+        // ---- x = H(0:j-1, j): its owners publish it ----
+        if (tc == tcj) {
+#pragma unroll
+            for (int p = 0; p < PR; ++p) {
+                T xv = zero;
+#pragma unroll
+                for (int q = 0; q < PC; ++q) xv = sel(q == qj, a[p][q], xv);
+                if (tr + WTR * p < j) xs[buf][tr + WTR * p] = xv;
+            }
+        }
+        __syncthreads();
+        // ---- larfg scalars, redundantly per wave (zhetd2_gpu.F90:60-100) ----
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < NMAX / 64; ++u) {
+            const int r = lane + 64 * u;
+            const T xv = xs[buf][min(r, j - 1)];
+            ss += (r < j - 1) ? abs2_(xv) : 0.0;
+        }
+        ss = wave_sum(ss);
+        double beta;
+        T tauj, scale;
+        larfg_scalars<T>(ss, xs[buf][j - 1], beta, tauj, scale);
+        auto vat = [&](int r) -> T {      // v(r): scale * x(r), 1 at r = j-1, 0 from j on
+            const T xv = xs[buf][min(r, j - 1)];
+            return sel(r < j - 1, scale * xv, sel(r == j - 1, Tr<T>::one(), zero));
+        };
+        T vr[PR], vc[PC], wr[PR];
+#pragma unroll
+        for (int p = 0; p < PR; ++p) vr[p] = vat(tr + WTR * p);
+#pragma unroll
+        for (int q = 0; q < PC; ++q) vc[q] = vat(tc + WTC * q);
+        const bool nz = !(real_(tauj) == 0.0 && imag_(tauj) == 0.0);
+        if (nz) {
+            // ---- y = H v on rows < j: own rows x own columns, then the half-wave sum over tc ----
+#pragma unroll
+            for (int p = 0; p < PR; ++p) {
+                wr[p] = zero;
+                if (p < kp) {
+                    T acc = zero;
+#pragma unroll
+                    for (int q = 0; q < PC; ++q)
+                        if (q < kq) fma_(acc, a[p][q], vc[q]);
+                    wr[p] = half_sum32(acc);
+                }
+            }
+            if (tc == 0) {
+#pragma unroll
+                for (int p = 0; p < PR; ++p)
+                    if (tr + WTR * p < j) ys[buf][tr + WTR * p] = wr[p];
+            }
+            __syncthreads();
+            // ---- alpha = -1/2 tau (p^H v), p = tau y; w = p + alpha v  (zhetd2_gpu.F90:120-160) ----
+            T dd = zero;
+#pragma unroll
+            for (int u = 0; u < NMAX / 64; ++u) {
+                const int r = lane + 64 * u;
+                const T pv = sel(r < j, tauj * ys[buf][min(r, j - 1)], zero);
+                fmac_(dd, pv, vat(r));
+            }
+            dd = wave_sum(dd);
+            const T al = (-0.5 * tauj) * dd;
+#pragma unroll
+            for (int p = 0; p < PR; ++p) wr[p] = sel(tr + WTR * p < j, tauj * wr[p] + al * vr[p], zero);
+            // ---- H -= v w^H + w v^H on rows, columns < j ----
+#pragma unroll
+            for (int q = 0; q < PC; ++q) {
+                if (q < kq) {
+                    const int cc = tc + WTC * q;
+                    const T wcq = sel(cc < j, tauj * ys[buf][min(cc, j - 1)] + al * vc[q], zero);
+                    const T vcc = conj_(vc[q]), wcc = conj_(wcq);
+#pragma unroll
+                    for (int p = 0; p < PR; ++p) {
+                        if (p < kp) {
+                            T t = a[p][q];
+                            t = t - (vr[p] * wcc + wr[p] * vcc);
+                            a[p][q] = sel(tr + WTR * p == cc, Tr<T>::realpart(t), t);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- column j now stores the reflector; superdiagonal as the reference leaves it ----
+        if (tc == tcj) {
+            const T sup = j < 32 ? Tr<T>::make(beta, 0.0) : Tr<T>::one();
+#pragma unroll
+            for (int p = 0; p < PR; ++p) {
+                const int r = tr + WTR * p;
+                const T nv = sel(r == j - 1, sup, vr[p]);
+#pragma unroll
+                for (int q = 0; q < PC; ++q) a[p][q] = sel(q == qj && r < j, nv, a[p][q]);
+            }
+        }
+        if (tid == 0) { e[j - 1] = beta; tau[j - 1] = tauj; }
+    }
+    // ---- d, and the upper triangle back to A ----
+#pragma unroll
+    for (int p = 0; p < PR; ++p)
+#pragma unroll
+        for (int q = 0; q < PC; ++q) {
+            const int r = tr + WTR * p, cc = tc + WTC * q;
+            if (r < n && cc < n && r <= cc) {
+                A[(size_t)r + (size_t)cc * lda] = a[p][q];
+                if (r == cc) d[r] = real_(a[p][q]);
+            }
+        }
+}
+template <class T> constexpr int wide_pc() { return Tr<T>::cx ? 4 : 6; }          // order 128 (complex) / 192 (real)
+template <class T> constexpr int wide_nmax() { return WTC * wide_pc<T>(); }
+
 template <class T> __global__ void __launch_bounds__(256) diag_extract_kernel(int n0, int n, const T* A, int lda, double* d) {
     int j = n0 + blockIdx.x * 256 + threadIdx.x;
     if (j < n) d[j] = real_(A[(size_t)j + (size_t)j * lda]);  // zhetrd_gpu.F90:89-94
@@ -1041,14 +791,9 @@ static int hemv_grid(const Ctx& c, int n) {
     long ntiles = (long)nt * (nt + 1) / 2;
     long cap = c.hemv_blocks > 0 ? c.hemv_blocks : 2L * c.n_cu;  // = resident workgroups (2 per CU): one wave of blocks, no tail
     if (ntiles <= cap) return (int)ntiles;
-    // Tile-round quantisation: workgroup b takes tiles b, b+G, b+2G, ...  With G = cap, 528 tiles (n = 2048) are one full
-    // round plus 16 tiles that run alone.  Spreading the tiles evenly over the minimum number of rounds (G = 264 x 2 tiles)
-    // was measured SLOWER (n=2048: 10.1 vs 9.0 us per launch; C3 tridiagonalization 71.2 vs 69.2 ms): two resident
-    // workgroups per CU hide more latency than the balanced tail saves.  Kept as option "hemv_balance" (off).
-    if (c.hemv_balance > 0) {   // k: balance when the tiles make at least k rounds
-        long rounds = (ntiles + cap - 1) / cap;
-        if (rounds >= c.hemv_balance) return (int)((ntiles + rounds - 1) / rounds);
-    }
+    // Workgroup b takes tiles b, b+G, b+2G, ... with G = the resident workgroups.  (Spreading the tiles evenly over the minimum
+    // number of rounds was measured SLOWER in round 2 -- n=2048: 10.1 vs 9.0 us per launch -- two resident workgroups per CU
+    // hide more latency than a balanced tail saves.)
     return (int)cap;
 }
 
@@ -1078,41 +823,10 @@ template <class T> static TrdScratch<T> trd_scratch(Ctx& c, int N, int prob = 0)
     return s;
 }
 
-// double-buffered partial-sum sets of the one-launch-per-column path (panel_col_kernel), sized for order nmax
-template <class T> struct ColScratch {
-    T* x[2]; T* P[2]; T* S[2]; T* D[2]; T* Zp[2]; T* alpha[2];
-    double* NP[2];
-    int ldp;
-};
-template <class T> static ColScratch<T> col_scratch(Ctx& c, int nmax, int prob = 0) {
-    ColScratch<T> s;
-    const int nt = nmax / HT + 1;
-    s.ldp = nt * HT;
-    const size_t per = (size_t)(nt * HT + 64) + (size_t)nt * s.ldp + (size_t)(nt * (nt + 1) / 2 + 64) + (size_t)(nt + 64) +
-                       (size_t)(nt + 1) * 2 * NBMAX + 8;
-    char nm[32];
-    snprintf(nm, sizeof nm, prob == 0 ? "trd_col" : "trd_col#%d", prob);
-    T* base = c.scratch<T>(nm, 2 * per);
-    snprintf(nm, sizeof nm, prob == 0 ? "trd_colNP" : "trd_colNP#%d", prob);
-    double* np = c.scratch<double>(nm, 2 * (size_t)(nt + 64));
-    for (int b = 0; b < 2; ++b) {
-        T* q = base + (size_t)b * per;
-        s.x[b] = q; q += nt * HT + 64;
-        s.P[b] = q; q += (size_t)nt * s.ldp;
-        s.S[b] = q; q += nt * (nt + 1) / 2 + 64;
-        s.D[b] = q; q += nt + 64;
-        s.Zp[b] = q; q += (size_t)(nt + 1) * 2 * NBMAX;
-        s.alpha[b] = q;
-        s.NP[b] = np + (size_t)b * (nt + 64);
-    }
-    return s;
-}
-
 // one problem of a lockstep batch: its matrix, outputs, panel workspace and private scratch
 template <class T> struct TrdProb {
     T* A; double* d; double* e; T* tau; T* W;
     TrdScratch<T> sc;
-    ColScratch<T> cs;
 };
 
 template <class T, int NB>
@@ -1124,7 +838,6 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
         PanelArgs<T>& a = ab.p[q];
         a.A = P.A; a.lda = lda; a.W = P.W; a.ldw = ldw; a.np = np; a.nb = nb; a.e = P.e; a.tau = P.tau;
         a.xbuf = P.sc.xbuf; a.P = P.sc.P; a.ldp = P.sc.ldp; a.S = P.sc.S; a.Zp = P.sc.Zp; a.NP = P.sc.NP; a.alphaSlot = P.sc.alphaSlot;
-        a.wt = c.p_wt;
     }
     auto set_all = [&](auto f) { for (int q = 0; q < NB; ++q) f(ab.p[q]); };
     int gh_prev = 0, nchunk_prev = 0;
@@ -1155,90 +868,47 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
     EIG_HIP(hipGetLastError());
 }
 
-// One panel through panel_col_kernel: nb launches (one per column) + the finish-only launch for the panel's leftmost column.
-template <class T, int NB>
-static void latrd_panel_fused(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr, int np, int nb, int lda, int ldw,
-                              bool sweep_only = false, long* nlaunch = nullptr, double* algo_bytes = nullptr) {
-    ColBatch<T, NB> ab;
-    auto fill = [&](int i) {
-        for (int q = 0; q < NB; ++q) {
-            const TrdProb<T>& P = pr[q < nprob ? q : 0];
-            ColArgs<T>& a = ab.p[q];
-            const int nw = i & 1, pv = (i + 1) & 1;       // set written by this launch / set of the previous launch
-            a.A = P.A; a.lda = lda; a.W = P.W; a.ldw = ldw; a.np = np; a.nb = nb; a.i = i; a.d = P.d; a.e = P.e; a.tau = P.tau;
-            a.xprev = P.cs.x[pv]; a.xnew = P.cs.x[nw];
-            a.Pp = P.cs.P[pv]; a.Pn = P.cs.P[nw]; a.ldp = P.cs.ldp;
-            a.Sp = P.cs.S[pv]; a.Sn = P.cs.S[nw];
-            a.Dp = P.cs.D[pv]; a.Dn = P.cs.D[nw];
-            a.NPp = P.cs.NP[pv]; a.NPn = P.cs.NP[nw];
-            a.Zpp = P.cs.Zp[pv]; a.Zpn = P.cs.Zp[nw];
-            a.alphap = P.cs.alpha[pv]; a.alphan = P.cs.alpha[nw];
-        }
-    };
-    for (int i = np - 1; i >= np - nb; --i) {
-        fill(i);
-        const int nt = i / HT + 1;                   // tiles over rows 0 .. i (row i has an owner even when i % 64 == 0)
-        const dim3 grid(nt * (nt + 1) / 2, nprob);
-        if (i == np - 1) hipLaunchKernelGGL((panel_col_kernel<T, NB, true, false>), grid, dim3(CTH), 0, st, ab);
-        else hipLaunchKernelGGL((panel_col_kernel<T, NB, false, false>), grid, dim3(CTH), 0, st, ab);
-        if (nlaunch) ++*nlaunch;
-        if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)i * (double)(i + 1) * 0.5;
-    }
-    if (!sweep_only) {
-        const int cfin = np - nb;                    // the panel's leftmost column: finished, nothing generated
-        fill(cfin - 1);
-        const int ntc = (cfin + HT - 1) / HT;
-        hipLaunchKernelGGL((panel_col_kernel<T, NB, false, true>), dim3(ntc, nprob), dim3(CTH), 0, st, ab);
-    }
-    EIG_HIP(hipGetLastError());
+// Order at which the blocked reduction stops and the one-workgroup kernel takes over: option "trd_finish" (-1 = the largest
+// order hetd2_wide_kernel holds, 32 = the reference's cut-over with the LDS kernel hetd2_kernel; values in between are allowed).
+template <class T> static int finish_order(const Ctx& c) {
+    const int nmax = wide_nmax<T>();
+    if (c.trd_finish < 0) return nmax;
+    return c.trd_finish <= TD ? TD : (c.trd_finish > nmax ? nmax : c.trd_finish);
+}
+template <class T> static void launch_finish(hipStream_t st, int nx, int n0, T* A, int lda, double* d, double* e, T* tau) {
+    if (nx <= TD) hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, A, lda, d, e, tau);
+    else hipLaunchKernelGGL((hetd2_wide_kernel<T, wide_pc<T>()>), dim3(1), dim3(WTR * WTC), 0, st, n0, A, lda, d, e, tau);
 }
 
 // nprob problems of order N reduced in lockstep: every per-column launch carries all of them (blockIdx.y); the trailing
-// rank-2nb updates and the final 32x32 blocks are launched per problem.  nprob = 1 is the plain zhetrd_gpu path.
-// panels whose trailing order is <= this go through panel_col_kernel (one launch per column); option "trd_fuse"
-template <class T> static int trd_fuse_order(const Ctx& c) {
-    if (c.trd_fuse >= 0) return c.trd_fuse;
-    return Tr<T>::cx ? kTrdFuseZ : kTrdFuseD;
-}
-
+// rank-2nb updates and the final blocks are launched per problem.  nprob = 1 is the plain zhetrd_gpu path.
 template <class T, int NB>
 static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdProb<T>* pr, int lda, int nb) {
     if (N <= 0) return;
     if (nb <= 0 || nb > NBMAX) nb = NBMAX;
-    const int nx = TD;
+    const int nx = finish_order<T>(c);
     const int ldw = N;
     int np = N;
     auto trailing = [&](int npn, int nbn) {
         for (int q = 0; q < nprob; ++q)
             her2k_un<T>(c, st, npn - nbn, nbn, pr[q].A + (size_t)(npn - nbn) * lda, lda, pr[q].W, ldw, pr[q].A, lda);
     };
-    const int fuse_n = trd_fuse_order<T>(c);
-    int fused_from = 0;                               // columns below this were reduced by panel_col_kernel, which stores d itself
-    auto panel = [&](int npn, int nbn) {
-        if (npn <= fuse_n) {
-            if (fused_from == 0) fused_from = npn;
-            latrd_panel_fused<T, NB>(c, st, nprob, pr, npn, nbn, lda, ldw);
-        } else {
-            latrd_panel<T, NB>(c, st, nprob, pr, npn, nbn, lda, ldw);
-        }
-    };
     while (np - nb >= nx) {  // zhetrd_gpu.F90:60-71
-        panel(np, nb);
+        latrd_panel<T, NB>(c, st, nprob, pr, np, nb, lda, ldw);
         trailing(np, nb);
         np -= nb;
     }
     int nbr = np - nx;  // remainder panel, :73-83
     if (nbr > 0) {
-        panel(np, nbr);
+        latrd_panel<T, NB>(c, st, nprob, pr, np, nbr, lda, ldw);
         trailing(np, nbr);
         np = nx;
     }
     int n0 = N < nx ? N : nx;
     for (int q = 0; q < nprob; ++q) {
-        hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);
-        const int x0 = fused_from > n0 ? fused_from : n0;
-        if (N > x0)
-            hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - x0 + 255) / 256), dim3(256), 0, st, x0, N, (const T*)pr[q].A, lda,
+        launch_finish<T>(st, nx, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);   // :86-87
+        if (N > n0)
+            hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - n0 + 255) / 256), dim3(256), 0, st, n0, N, (const T*)pr[q].A, lda,
                                pr[q].d);
     }
     EIG_HIP(hipGetLastError());
@@ -1247,7 +917,7 @@ static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdPr
 template <class T>
 void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb) {
     if (N <= 0) return;
-    TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N), col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)))};
+    TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N)};
     hetrd_lockstep<T, 1>(c, st, N, 1, &pr, lda, nb);
 }
 
@@ -1260,8 +930,7 @@ void hetrd_upper_batch(Ctx& c, hipStream_t st, int N, int nprob, T* const* A, in
         const int nq = nprob - q0 < MAXB ? nprob - q0 : MAXB;
         TrdProb<T> pr[MAXB];
         for (int q = 0; q < nq; ++q)
-            pr[q] = TrdProb<T>{A[q0 + q], d[q0 + q], e[q0 + q], tau[q0 + q], W[q0 + q], trd_scratch<T>(c, N, q),
-                               col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)), q)};
+            pr[q] = TrdProb<T>{A[q0 + q], d[q0 + q], e[q0 + q], tau[q0 + q], W[q0 + q], trd_scratch<T>(c, N, q)};
         if (nq == 1) hetrd_lockstep<T, 1>(c, st, N, 1, pr, lda, nb);
         else hetrd_lockstep<T, MAXB>(c, st, N, nq, pr, lda, nb);
     }
@@ -1281,16 +950,11 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     EIG_HIP(hipMemcpyAsync(sc.xbuf, A, sizeof(T) * N, hipMemcpyDeviceToDevice, st));
     c.sync(st);
     *nlaunch = 0; *algo_bytes = 0.0;
-    const int nx = TD;
+    const int nx = finish_order<T>(c);
     int np = N;
     double* dsink = c.scratch<double>("sweep_d", (size_t)N + 8);
-    TrdProb<T> pr{A, dsink, e, tau, W, sc, col_scratch<T>(c, min(N, max(trd_fuse_order<T>(c), 64)))};
-    const int fuse_n = trd_fuse_order<T>(c);
-    auto panel = [&](int npn, int nbn) {
-        // (below the fuse order the mat-vec IS the one-launch-per-column kernel: row work + tile, as the reduction runs it)
-        if (npn <= fuse_n) latrd_panel_fused<T, 1>(c, st, 1, &pr, npn, nbn, lda, N, true, nlaunch, algo_bytes);
-        else latrd_panel<T, 1>(c, st, 1, &pr, npn, nbn, lda, N, true, nlaunch, algo_bytes);
-    };
+    TrdProb<T> pr{A, dsink, e, tau, W, sc};
+    auto panel = [&](int npn, int nbn) { latrd_panel<T, 1>(c, st, 1, &pr, npn, nbn, lda, N, true, nlaunch, algo_bytes); };
     while (np - nb >= nx) {
         panel(np, nb);
         np -= nb;
@@ -1306,7 +970,7 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     PanelArgs<T>& a = ab.p[0];
     a.A = const_cast<T*>(A); a.lda = lda; a.W = nullptr; a.ldw = 0; a.np = n + 1; a.nb = 1; a.i = n;
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
-    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0; a.wt = c.p_wt;
+    a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
     a.gh = hemv_grid(c, n);
     hipLaunchKernelGGL((panel_mv_kernel<T, 1>), dim3(a.gh), dim3(MVT), 0, st, ab, 1, 0);
     if (gather) {

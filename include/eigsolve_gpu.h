@@ -38,38 +38,42 @@ int eigsolve_set_lapack(const char *path);
 /* Caps the host LAPACK thread count (OpenBLAS builds only; no-op otherwise). */
 int eigsolve_set_host_threads(int nthreads);
 
-/* Tunables (reference hard-codes them: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64
- * :64, gst nb=448 zhegvdx_gpu.F90:156).  name in {"trd_nb","bt_nb","hemv_blocks","tridiag","graph","overlap","gst","gst_thr","trsm_base","potrf","real_il_reference","p_wt","hemv_balance","batch_workers","batch_fuse"};
- * value<=0 restores the default, except where 0 is itself a setting: "tridiag", "gst", "overlap" (value<0 restores the
- * default), "potrf" (0 = recursive form, anything else = block rows), "batch_workers" (0 = lockstep form, value<0 or >16 = automatic).  "tridiag": 0 = host LAPACK dstedc exactly as the reference
- * (also EIGSOLVE_TRIDIAG=host), 1 = device-side divide & conquer (default).  "graph": 1 = the
- * tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working copy of A
- * and replayed as a hipGraph; 0 (default) = eager launches (measured neutral: the dispatch latency is device-side).
- * "overlap": bit mask of independent launch chains of one solve that run on a second stream (leased from the library's stream
- * pool for the call): bit 0 = the latency-bound second half of potrf beside the part of hegst that only needs the first half
- * of the factor, bit 1 = larft T factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work).
- * Default 3.  Same kernels, operands and order of operations per block: results are bit-identical to "overlap" 0.  Only
- * applied to a solve that has the device to itself (no other call of this library in flight, not inside a batch call):
- * C3 isolated solve 95.7 -> 94.0 ms.
- * "bt_nb": reflectors per block of the back-transformation: 64 (the reference's larfb width), 128, 256 (default) or 512 --
- * 64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
- * "batch_workers": problems kept in flight inside one eigsolve_?hegvdx_batch call (default automatic: 4 when the process allows
- * >= 5 hardware queues through GPU_MAX_HW_QUEUES, else 3; 0 = lockstep form).
- * "batch_fuse": problems per launch chain of a batch call that share the per-column launches of the tridiagonalization (lockstep
- * groups, 1..4; default automatic: min(4, problems / chains) while a matrix is <= 96 MiB -- complex N <= 2508, real N <= 3547 --,
- * else 1): C5 (64 x zhegvdx N=2048) 83.8 -> 98 problems/s, complex N = 1024 246 -> 361; bit-identical per-problem results.
- * "gst": reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
- * triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal blocks are
- * larger than "gst_thr" (default 1024), two solves below.
- * "trsm_base": order of the inverted diagonal blocks the triangular solves outside potrf stop at, 64 or 256 (default:
- * the 64-block inverses of the factorization merged into 256-block inverses, 4x fewer launches per solve).
- * "potrf": 1 (default) right-looking Cholesky with block rows of 64 (one block-row kernel + one rank-64 MFMA update per block
- * row), 0 the recursive form.  "gst" also accepts 3 = the reference's blocked
- * loop (zhegst_gpu.F90:51-107) with nb = "trsm_base"; "trsm_base" also accepts 512 / 1024 (inverse blocks merged on MFMA).
- * "real_il_reference": 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
- * (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).
- * "p_wt", "hemv_balance" (k: spread the mat-vec tiles evenly when they make >= k rounds): measured-and-rejected variants of the
- * panel mat-vec kernel (off).
+/* Tunables (the reference hard-codes its own: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64 :64, gst nb=448
+ * zhegvdx_gpu.F90:156).  Every option is also read from the environment variable EIGSOLVE_<NAME> (upper case, same values;
+ * TRIDIAG additionally accepts "host" / "device", POTRF "rec") when a context is created.  value <= 0 restores the default,
+ * except where 0 is itself a setting (then value < 0 restores the default).
+ *   "tridiag"   0 = host LAPACK dstedc exactly as the reference, 1 = device-side divide & conquer (default).
+ *   "trd_nb"    panel width of the tridiagonalization, 1..64 (default 64; the caller's workspace contract bounds it).
+ *   "trd_finish" order at which the blocked reduction hands the rest of the matrix to a one-workgroup kernel: -1 (default) =
+ *               128 (complex) / 192 (real), the matrix then lives in the registers of one CU; 32 = the reference's cut-over
+ *               (zhetrd_gpu.F90:84-87).
+ *   "bt_nb"     reflectors per block of the back-transformation: 64 (the reference's larfb width), 128, 256 (default) or 512 --
+ *               64-blocks whose T factors are merged pairwise, so the rank-k updates run at K = bt_nb.
+ *   "gst"       reduction to standard form, 0 = symmetric recursion of zhegst_gpu.F90:51-107 down to 64x64 blocks, 1 = two full
+ *               triangular solves on a Hermitian-completed copy, 2 (default) = the symmetric algorithm while the diagonal
+ *               blocks are larger than "gst_thr" (default 1024), two solves below, 3 = the reference's blocked loop with
+ *               nb = "trsm_base".
+ *   "trsm_base" order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64, 256 (default: the
+ *               64-block inverses of the factorization merged), 512 or 1024.
+ *   "potrf"     1 (default) right-looking Cholesky with block rows of 64 (one block-row kernel + one rank-64 MFMA update per
+ *               block row), 0 the recursive form (no intra-grid dependency).
+ *   "overlap"   bit mask of independent launch chains of one solve that run on a second stream (leased from the library's
+ *               stream pool for the call): bit 0 = hegst beside the factorization, released stage by stage, bit 1 = larft T
+ *               factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work).  Default 3.  Same
+ *               kernels, operands and order of operations per block: results are bit-identical to "overlap" 0.  Only applied
+ *               to a solve that has the device to itself (best effort: no other call of this library in flight, not inside a
+ *               batch call).
+ *   "batch_workers" problems kept in flight inside one eigsolve_?hegvdx_batch call (default automatic: 4 when the process
+ *               allows >= 5 hardware queues through GPU_MAX_HW_QUEUES, else 3; 0 = lockstep form on the caller's context).
+ *   "batch_fuse" problems per launch chain of a batch call that share the per-column launches of the tridiagonalization
+ *               (lockstep groups, 1..4; default automatic: min(4, problems / chains) while a matrix is <= 96 MiB, else 1).
+ *   "real_il_reference" 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
+ *               (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).
+ *   "graph"     1 = the tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working
+ *               copy of A and replayed as a hipGraph; 0 (default) = eager launches (measured neutral).
+ *   "tile_map"  1 (default) = XCD-aware super-tile order of the MFMA engine's workgroups, 0 = plain grids (A/B measurements).
+ *   "hemv_blocks" workgroups of the panel mat-vec kernel (0 = automatic: two per CU).
+ *   "trace_marks" 1 = marker kernels at the phase boundaries (segments a rocprofv3 kernel trace, tools/trace_phases.py).
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

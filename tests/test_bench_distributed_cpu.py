@@ -96,3 +96,15 @@ def test_bench_uses_the_batch_module():
     src = open(os.path.join(ROOT, "bench.py")).read()
     for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems", "host_threads_per_rank"):
         assert name in src
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N must mean N ranks: with WORLD_SIZE set by a launcher to something else the script refuses to run
+    (before it touches a GPU) instead of labelling a 1-rank measurement as an N-GPU one; launched plainly with --gpus N > 1 it
+    re-executes itself under torch.distributed.run (GPU test: test_bench_gpus_flag_starts_its_own_ranks)."""
+    envv = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300, env=envv)
+    assert out.returncode != 0
+    assert "--gpus 4 but WORLD_SIZE=1" in (out.stdout + out.stderr)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "torch.distributed.run" in src and "args.gpus" in src

@@ -318,32 +318,40 @@ def test_hetrd_vs_oracle(env, cplx, n, nb, fam):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("n,fuse", [(200, 4096), (411, 4096), (700, 300), (129, 64)])
-def test_hetrd_one_launch_per_column_path(env, cplx, n, fuse):
-    """Option trd_fuse: panels of trailing order <= fuse go through panel_col_kernel (row work folded into the mat-vec launch,
-    larfg scalars applied one launch later by linearity; off by default, measured slower).  d, e, tau and the reflectors must
-    agree with the oracle like the default path's, incl. orders where a column index is a multiple of 64 (ownerless row) and
-    the switch from the two-kernel path inside one reduction (n = 700, fuse = 300)."""
+@pytest.mark.parametrize("n,finish", [(33, -1), (100, -1), (128, -1), (129, -1), (192, -1), (193, -1), (200, 96), (411, -1), (411, 32), (700, 64)])
+def test_hetrd_one_workgroup_finish(env, cplx, n, finish):
+    """Option trd_finish: the order at which the blocked reduction hands the rest of the matrix to ONE workgroup
+    (hetd2_wide_kernel: matrix in registers, order <= 128 complex / 192 real; 32 = the reference's cut-over,
+    zhetrd_gpu.F90:84-87 + zhetd2_gpu.F90).  d, e, tau and the reflectors must agree with the reference-structured oracle
+    exactly like the reference's own cut-over does -- incl. orders that fit the kernel entirely (n <= 128 / 192), orders one
+    above its capacity, and cut-overs in between."""
     torch, oracle, api = env
-    A = oracle.gen_spd(n, 5000 + n, cplx) if n < 200 else oracle.gen_spd_fast(n, 5000 + n, cplx)
+    A = oracle.gen_spd(n, 5000 + n, cplx, shift=float(n)) if n < 200 else oracle.gen_spd_fast(n, 5000 + n, cplx)
     Ao, do, eo, tauo = oracle.hetrd(np.triu(A), nb=32)
-    Ad = api.to_device(np.triu(A))
+    Ain = np.triu(A).copy()
+    Ain[np.tril_indices(n, -1)] = -3.25
+    Ad = api.to_device(Ain)
     try:
-        assert api.set_option("trd_fuse", fuse) == 0
+        assert api.set_option("trd_finish", finish) == 0
         d, e, tau = api.hetrd(Ad)
     finally:
-        api.set_option("trd_fuse", -1)
-    d, e = d.cpu().numpy(), e.cpu().numpy()
-    scale = np.linalg.norm(A, 2)                 # backward-error scale, as in test_hetrd_vs_oracle
-    tol = 200 * n * EPS * scale
-    assert np.abs(d - do).max() <= tol and np.abs(np.abs(e) - np.abs(eo)).max() <= tol
+        api.set_option("trd_finish", -1)
+    d, e, tau = d.cpu().numpy(), e.cpu().numpy(), tau.cpu().numpy()
+    scale = np.linalg.norm(oracle.herm_from_upper(A), 2)      # backward-error scale, as in test_hetrd_vs_oracle
+    tol = 200 * max(n, 8) * EPS * scale
+    assert np.abs(d - do).max() <= tol and np.abs(e - eo).max() <= tol
+    got = api.to_host(Ad)
+    if n < 200:     # (shifted family: forward quantities are well conditioned)
+        assert np.abs(tau - tauo).max() <= 1e-7
+        assert rel(np.triu(got, 1), np.triu(Ao, 1)) <= 1e-7
     # eigenvalues of the tridiagonal matrix = eigenvalues of A
     import scipy.linalg as sl
     wt = sl.eigvalsh_tridiagonal(d, e)
-    wa = np.linalg.eigvalsh(A)
+    wa = np.linalg.eigvalsh(oracle.herm_from_upper(A))
     assert np.abs(wt - wa).max() <= 200 * n * EPS * np.abs(wa).max()
-    Ah = api.to_host(Ad)
-    assert np.array_equal(np.tril(Ah, -1), np.zeros_like(np.tril(Ah, -1)))      # nothing written below the diagonal
+    assert np.all(got[np.tril_indices(n, -1)] == -3.25)         # nothing written below the diagonal
+    for j in range(1, n):                                        # superdiagonal exactly as the reference leaves it
+        assert got[j - 1, j] == (e[j - 1] if j < 32 else 1.0)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -1231,6 +1239,67 @@ def test_contexts_die_with_their_threads(env):
     assert grown < 64 * 2 ** 20, "device memory grew by %.0f MB over 12 short-lived threads" % (grown / 2 ** 20)
 
 
+def test_finalize_after_batches_and_from_two_threads(env):
+    """eigsolve_finalize after a batch call (the library's worker threads hold contexts of their own): every worker releases
+    its context and the call returns; two threads finalizing at the same time do not deadlock (the spin barrier of
+    the first version could split the pool threads between two finalizers for ever); the next solve / batch re-creates
+    what it needs and gives the same results; device memory goes back."""
+    import threading
+    torch, oracle, api = env
+    n, m, nprob = 300, 60, 4
+    probs = [(oracle.gen_spd_fast(n, 4100 + q, True), oracle.gen_spd_fast(n, 4200 + q, True, shift=float(n))) for q in range(nprob)]
+
+    def run_batch():
+        pairs = [(api.to_device(np.triu(a)), api.to_device(np.triu(b))) for a, b in probs]
+        wss = [api.Workspace(n, True) for _ in range(nprob)]
+        assert api.hegvdx_batch(pairs, 1, m, wss) == [0] * nprob
+        return [ws.w_h.clone() for ws in wss]
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return total - free
+
+    assert api.set_option("batch_workers", 3) == 0
+    try:
+        w0 = run_batch()
+        assert api.finalize() == 0
+        assert api.set_option("batch_workers", 3) == 0          # (options live in the context that was just released)
+        w1 = run_batch()
+        for a, b in zip(w0, w1):
+            assert torch.equal(a, b)
+        # two concurrent finalizers, each after a batch of its own thread
+        errs, done = [], []
+
+        def worker():
+            try:
+                torch.cuda.set_device(0)
+                api.set_option("batch_workers", 3)
+                run_batch()
+                assert api.finalize() == 0
+                done.append(1)
+            except Exception as ex:  # noqa: BLE001
+                errs.append(repr(ex))
+
+        ths = [threading.Thread(target=worker, daemon=True) for _ in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=120)
+        assert not errs, errs
+        assert len(done) == 2, "eigsolve_finalize did not return in both threads (deadlock)"
+        assert api.finalize() == 0
+        base = used()
+        api.set_option("batch_workers", 3)
+        w2 = run_batch()
+        for a, b in zip(w0, w2):
+            assert torch.equal(a, b)
+        assert api.finalize() == 0
+        assert used() - base < 64 * 2 ** 20, "finalize left %.0f MB of library scratch behind" % ((used() - base) / 2 ** 20)
+    finally:
+        api.set_option("batch_workers", -1)
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 def test_liwork_contract(env, cplx):
     """liwork_h: the reference announces 3+5N but rejects only < N (zhegvdx_gpu.F90:123).  Device tridiagonal solver:
@@ -1322,6 +1391,30 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["config"]["problems_per_step_total"] == 64 and d["config"]["problems_per_gpu_per_step"] == 32
     assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(env):
+    """`python bench.py --gpus 2` launched PLAINLY (no torchrun, no WORLD_SIZE): the script re-executes itself under
+    torch.distributed.run with one rank per GPU (the flag used to be parsed and ignored, so a scaling run
+    started this way measured one GPU at every point).  Also: a world size that contradicts --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--order", "384",
+           "--c5-order", "256", "--share-gpu", "--backend", "gloo", "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag",
+           "--batch", "2", "--isolated-reps", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=envv)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["comm"]["ranks"] == 2 and d["comm"]["backend"] == "gloo"
+    assert d["config"]["problems_per_step_total"] == 4 and d["config"]["problems_per_gpu_per_step"] == 2
+    assert d["strict_gate"]["pass"] is True and d["strict_gate"]["residual"] <= d["strict_gate"]["bound_N_eps"]
+    # contradiction: one process, --gpus 2 claimed through a foreign WORLD_SIZE=1
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(envv, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in (out.stdout + out.stderr)
 
 
 def test_bench_eight_ranks_on_one_gpu(env):
