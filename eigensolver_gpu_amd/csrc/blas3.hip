@@ -109,8 +109,18 @@ __device__ __forceinline__ void trim_k(const Operand<T>& o, int i0, int bsz, int
     }
 }
 
-constexpr int BKL = 16;  // K-slab of the 64x64 tiles
-constexpr int BKS = 32;  // K-slab of the 32x32 tiles: K <= 64 (panel-sized products) is two stages
+// K-slabs.  A slab of a complex 64x64 tile at BK = 16 is 256 MFMAs per wave (4096 cycles) between two barriers; the same
+// slab of a real tile is 64 MFMAs (1024 cycles), so the per-slab cost (barrier, LDS write -> read turn-around) weighs four times
+// as much: real tiles take slabs twice as deep (same LDS bytes per stage as the complex ones).
+#ifndef EIG_BKL_REAL
+#define EIG_BKL_REAL 16
+#endif
+#ifndef EIG_BKS_REAL
+#define EIG_BKS_REAL 32
+#endif
+constexpr int BKL = 16;  // K-slab of the 64x64 tiles (complex)
+constexpr int BKS = 32;  // K-slab of the 32x32 tiles (complex): K <= 64 (panel-sized products) is two stages
+template <class T> constexpr int slab_k(bool small) { return Tr<T>::cx ? (small ? BKS : BKL) : (small ? EIG_BKS_REAL : EIG_BKL_REAL); }
 
 // ------------------------------------------------------------------------------------------------
 // gemm_fast_kernel
@@ -483,7 +493,7 @@ template <class T> static dim3 choose_map(GemmArgs<T>& g, int tm, int tn, bool t
 
 template <class T, int BM, int BN>
 static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map) {
-    constexpr int BK = (BM * BN <= 32 * 32) ? BKS : BKL;
+    constexpr int BK = slab_k<T>(BM * BN <= 32 * 32);
     GemmArgs<T> g = g_in;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const bool tri = g.epi.uplo != 0 && BM == BN && tm == tn;
