@@ -346,7 +346,6 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         // device-side divide & conquer: no N x N host round trip at all
         c.sync(st);
         pt.collect(PH_TRD);
-        if (hetrd_failed(c)) { printf(" eigsolve error: hetrd failed! (the workgroups of the finish kernel could not synchronise; use option trd_finish = 128)\n"); return -1; }
         if (ovT) build_T_beside();
         double t0 = now_ms();
         double* Qd = nullptr;
@@ -369,7 +368,6 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     if (N > 1) EIG_HIP(hipMemcpyAsync(e_h, e_d, sizeof(double) * (N - 1), hipMemcpyDeviceToHost, st));
     c.sync(st);
     pt.collect(PH_TRD);
-    if (hetrd_failed(c)) { printf(" eigsolve error: hetrd failed! (the workgroups of the finish kernel could not synchronise; use option trd_finish = 128)\n"); return -1; }
     if (ovT) build_T_beside();
     double t0 = now_ms();
     stedc_fn f = get_dstedc();
@@ -877,7 +875,6 @@ template <class T> static int hetrd_entry(int N, T* A, int lda, double* d, doubl
         if (!W || (long)lwork < (long)N * nb) W = c.scratch<T>("trd_W", (size_t)N * nb);
         hetrd_upper<T>(c, c.s1, N, A, lda, d, e, tau, W, nb);
         c.sync(c.s1);
-        if (hetrd_failed(c)) { printf(" eigsolve error: hetrd failed! (the workgroups of the finish kernel could not synchronise; use option trd_finish = 128)\n"); return -1; }
         return 0;
     });
 }

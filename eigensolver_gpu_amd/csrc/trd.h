@@ -9,10 +9,6 @@ namespace eig {
 template <class T>
 void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb);
 
-// After the stream has been synchronised: true if the multi-workgroup finish of the last hetrd_upper on this context could not
-// synchronise its workgroups (A is then unusable; option trd_finish = 128 / 192 avoids the in-launch exchange).
-bool hetrd_failed(const Ctx& c);
-
 // nprob problems of the same order in lockstep: every per-column launch of the panels carries all of them (arrays of
 // per-problem pointers; workspaces as for hetrd_upper).  Results per problem are bit-identical to hetrd_upper's.
 template <class T>

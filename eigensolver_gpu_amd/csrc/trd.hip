@@ -782,258 +782,6 @@ __global__ void __launch_bounds__(WTR * WTC) hetd2_wide_kernel(int n, T* A, int 
 template <class T> constexpr int wide_pc() { return Tr<T>::cx ? 4 : 6; }          // order 128 (complex) / 192 (real)
 template <class T> constexpr int wide_nmax() { return WTC * wide_pc<T>(); }
 
-// ------------------------------------------------------------------------------------------
-// hetd2_multi_kernel: the tail of the reduction (order <= 768 complex / 1024 real) on P co-resident workgroups, the matrix
-// resident in their REGISTERS, ONE in-launch exchange per column.
-//
-// Below n ~ 1300 a column of the two-kernel path costs ~9 us whatever the work (two chip-wide dependent launches).  Here the
-// full Hermitian matrix is dealt row-cyclically to P workgroups (row r lives in workgroup r mod P; 16 x PRL rows each, every
-// thread (tr, tc) of a 16 x 32 grid holds the entries (row, tc + 32 q) of its PRL rows).  Every workgroup keeps a replicated
-// copy of the CURRENT column x = H(0:j-1, j) in LDS and derives the larfg scalars and v redundantly (bit-identically); its
-// rows of y = H v need only its own registers (both triangles are stored) and a half-wave sum.  Then the one exchange of the
-// step: every workgroup publishes its <= 16 PRL entries of y, and the owner of row j-1 publishes that row -- the NEXT column
-// before this step's update -- so that after the exchange everybody can form w, update its rows AND update the replicated
-// next column locally: no second hand-over for x.  The exchange is placement-independent (MI355X_MICROARCH.md, "{sc1 stores,
-// sc1 loads}" form): write-through 16-/8-byte stores, every storing wave drained, ONE relaxed agent-scope flag per workgroup
-// and step (epoch = step number), one wave polls the P flags, payload read with L1-bypassing loads; buffers and flags are
-// double-buffered by step parity (a workgroup can only be one step ahead of the slowest one).  Measured price of this
-// exchange alone: 2.4 us per step at P = 32-48 (tools/microbench5.hip, profiles/r04_microbench5_exchange.txt).
-// All P workgroups must be co-resident (one per CU: 512 threads at up to 256 VGPRs); every spin is bounded by wall clock and
-// by a global error word, so a launch that cannot synchronise (CU mask, debugger) ends with *err = 1 -> info = -1, never hangs.
-// Outputs as hetd2_wide_kernel: d, e, tau, reflectors in the upper triangle, the reference's superdiagonal convention.
-// ------------------------------------------------------------------------------------------
-typedef double dd2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st_sc1(cplx* p, cplx v) {
-    dd2 t = {v.x, v.y};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-}
-__device__ __forceinline__ void st_sc1(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-// four L1-bypassing loads in flight, then waited for
-__device__ __forceinline__ void ld4_sc1(const cplx* p0, const cplx* p1, const cplx* p2, const cplx* p3, cplx& a, cplx& b, cplx& c, cplx& d) {
-    dd2 x, y, z, u;
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(x), "=&v"(y), "=&v"(z), "=&v"(u) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-    a = cplx{x.x, x.y}; b = cplx{y.x, y.y}; c = cplx{z.x, z.y}; d = cplx{u.x, u.y};
-}
-__device__ __forceinline__ void ld4_sc1(const double* p0, const double* p1, const double* p2, const double* p3, double& a, double& b, double& c,
-                                        double& d) {
-    asm volatile("global_load_dwordx2 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\tglobal_load_dwordx2 %2, %6, off sc1\n\t"
-                 "global_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
-}
-
-constexpr int MTH = 512;                // threads of a hetd2_multi_kernel workgroup
-constexpr int MULTI_PMAX = 64;          // workgroups (flag words per parity)
-// sum over the TCN lanes that share a thread row (TCN = 64: the wave, 32: a half wave), result in every lane of the group
-template <int TCN, class T> __device__ __forceinline__ T group_sum(T v) {
-    if constexpr (TCN == 64) return wave_sum(v);
-    else return half_sum32(v);
-}
-// Thread (tr, tc) of a TRN x TCN grid (TRN * TCN = 512) holds the entries (row, tc + TCN q), q < PC, of its PRL rows
-// row = w + P (tr + TRN p): PRL * PC register entries, every entry of v / w it needs is read from LDS ONCE per step (the
-// first version, a 16 x 32 grid with one row per thread, read v and w three times per entry and was LDS-bound:
-// profiles/r04_experiments.txt).  v and y are zero-padded in LDS up to the next multiple of TCN, so the inner loops
-// carry no masks: a column >= j contributes v = w = 0.
-template <class T, int TRN, int PRL, int PC>
-__global__ void __launch_bounds__(MTH) hetd2_multi_kernel(int n, int P, T* A, int lda, double* d, double* e, T* tau, T* Xg, T* Yg,
-                                                          unsigned* flags, int* err) {
-    constexpr int TCN = MTH / TRN, NMAX = TCN * PC;
-    static_assert(TCN == 64 || TCN == 32, "thread rows are waves or half waves");
-    static_assert(NMAX <= 2 * MTH, "two exchange entries per thread");
-    __shared__ T xs[2][NMAX];             // replicated columns: [cur] = x of this step, [cur ^ 1] = the next one
-    __shared__ T ys[NMAX], vs[NMAX];
-    __shared__ int fail;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tr = tid / TCN, tc = tid % TCN;
-    const T zero = Tr<T>::zero();
-    auto row_of = [&](int p) -> int { return w + P * (tr + TRN * p); };
-
-    T a[PRL][PC];
-#pragma unroll
-    for (int p = 0; p < PRL; ++p)
-#pragma unroll
-        for (int q = 0; q < PC; ++q) {
-            const int r = row_of(p), cc = tc + TCN * q;
-            const bool in = r < n && cc < n;
-            const int rl = min(r, n - 1), cl = min(cc, n - 1);
-            const T v = A[(size_t)min(rl, cl) + (size_t)max(rl, cl) * lda];      // stored upper triangle
-            T h = sel(r <= cc, v, conj_(v));
-            h = sel(r == cc, Tr<T>::realpart(h), h);
-            a[p][q] = sel(in, h, zero);
-        }
-    for (int i = tid; i < n - 1; i += MTH) xs[0][i] = A[(size_t)i + (size_t)(n - 1) * lda];
-    if (tid == 0) fail = 0;
-    __syncthreads();
-
-    int cur = 0;
-#if EIG_TRD_TIMING
-#define MSTAMP(PH) do { if (w == 0 && tid == 0) atomicAdd(&g_trd_stamp[2][PH], (unsigned long long)(__builtin_readcyclecounter() - MT0)); } while (0)
-#else
-#define MSTAMP(PH) do { } while (0)
-#endif
-    for (int j = n - 1; j >= 1; --j) {
-#if EIG_TRD_TIMING
-        const long long MT0 = __builtin_readcyclecounter();
-        if (w == 0 && tid == 0) atomicAdd(&g_trd_count[2], 1ULL);
-#endif
-        const unsigned step = (unsigned)(n - j);           // epoch of this step's exchange, 1, 2, ...
-        const int par = (int)(step & 1u);
-        T* const Xp = Xg + (size_t)par * NMAX;
-        T* const Yp = Yg + (size_t)par * NMAX;
-        unsigned* const fl = flags + par * MULTI_PMAX;
-        const int kq = (j + TCN - 1) / TCN;                 // register columns that still hold columns < j
-        const int jpad = kq * TCN;                          // v, y are zero-padded up to here
-        const T* const xc = xs[cur];
-        T* const xn = xs[cur ^ 1];
-        // ---- larfg scalars, redundantly per wave; v (zero-padded) into LDS ----
-        double ss = 0.0;
-#pragma unroll
-        for (int u = 0; u < NMAX / 64; ++u) {
-            if (64 * u < j - 1) {
-                const int r = lane + 64 * u;
-                const T xv = xc[min(r, j - 1)];
-                ss += (r < j - 1) ? abs2_(xv) : 0.0;
-            }
-        }
-        ss = wave_sum(ss);
-        double beta;
-        T tauj, scale;
-        larfg_scalars<T>(ss, xc[j - 1], beta, tauj, scale);
-        for (int i = tid; i < jpad; i += MTH) vs[i] = (i < j - 1) ? scale * xc[i] : ((i == j - 1) ? Tr<T>::one() : zero);
-        __syncthreads();
-        MSTAMP(0);
-        // ---- own rows of y = H v: v read once, kept for the update ----
-        T vc[PC], yl[PRL];
-#pragma unroll
-        for (int q = 0; q < PC; ++q) { vc[q] = zero; if (q < kq) vc[q] = vs[tc + TCN * q]; }
-#pragma unroll
-        for (int p = 0; p < PRL; ++p) {
-            T acc = zero;
-#pragma unroll
-            for (int q = 0; q < PC; ++q)
-                if (q < kq) fma_(acc, a[p][q], vc[q]);
-            yl[p] = group_sum<TCN>(acc);
-        }
-        MSTAMP(1);
-        // ---- the exchange: y entries of my rows; the owner of row j-1 adds that row (= the next column, before this update) ----
-        if (tc == 0) {
-#pragma unroll
-            for (int p = 0; p < PRL; ++p)
-                if (row_of(p) < j) st_sc1(Yp + row_of(p), yl[p]);
-        }
-        {
-            const int rj = j - 1;
-            if (rj % P == w) {
-                const int lrow = rj / P, trj = lrow % TRN, pj = lrow / TRN;
-#pragma unroll
-                for (int p = 0; p < PRL; ++p) {
-                    if (p == pj && tr == trj) {
-#pragma unroll
-                        for (int q = 0; q < PC; ++q) {
-                            const int cc = tc + TCN * q;
-                            if (q < kq && cc < rj) st_sc1(Xp + cc, conj_(a[p][q]));
-                        }
-                    }
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(fl + w, step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        MSTAMP(2);
-        if (wave == 0) {
-            const long long t0 = wall_clock64();
-            for (;;) {
-                bool ok = true;
-                if (lane < P) ok = (int)(__hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - step) >= 0;
-                if (__all(ok)) break;
-                __builtin_amdgcn_s_sleep(1);
-                const bool dead = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                                  wall_clock64() - t0 > 200000000LL;              // 2 s at 100 MHz
-                if (dead) {
-                    if (lane == 0) { fail = 1; __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        MSTAMP(3);
-        if (fail) break;
-        {
-            const int i0 = tid, i1 = tid + MTH;
-            T y0, y1, x0, x1;
-            ld4_sc1(Yp + min(i0, j - 1), Yp + min(i1, j - 1), Xp + min(i0, max(j - 2, 0)), Xp + min(i1, max(j - 2, 0)), y0, y1, x0, x1);
-            if (i0 < jpad) ys[i0] = sel(i0 < j, y0, zero);
-            if (i1 < jpad) ys[i1] = sel(i1 < j, y1, zero);
-            if (i0 < j - 1) xn[i0] = x0;
-            if (i1 < j - 1) xn[i1] = x1;
-        }
-        __syncthreads();
-        MSTAMP(4);
-        // ---- alpha = -1/2 tau (p^H v), p = tau y (every wave redundantly; the zero padding needs no masks) ----
-        T dd = zero;
-#pragma unroll
-        for (int u = 0; u < NMAX / 64; ++u)
-            if (64 * u < j) fmac_(dd, tauj * ys[lane + 64 * u], vs[lane + 64 * u]);
-        dd = wave_sum(dd);
-        const T al = (-0.5 * tauj) * dd;
-        MSTAMP(5);
-        // ---- H -= v w^H + w v^H on my rows, w = tau y + alpha v formed on the fly ----
-        T vr[PRL], wr[PRL];
-#pragma unroll
-        for (int p = 0; p < PRL; ++p) {
-            const int r = row_of(p);
-            const bool act = r < j;
-            const int rc = min(r, j - 1);
-            vr[p] = sel(act, vs[rc], zero);
-            wr[p] = sel(act, tauj * ys[rc] + al * vs[rc], zero);
-        }
-#pragma unroll
-        for (int q = 0; q < PC; ++q) {
-            if (q < kq) {
-                const int cc = tc + TCN * q;
-                const T wcc = conj_(tauj * ys[cc] + al * vc[q]), vcc = conj_(vc[q]);
-#pragma unroll
-                for (int p = 0; p < PRL; ++p) {
-                    T t = a[p][q] - (vr[p] * wcc + wr[p] * vcc);
-                    a[p][q] = sel(row_of(p) == cc, Tr<T>::realpart(t), t);
-                }
-            }
-        }
-        {   // the replicated next column: x(i) -= v(i) conj(w(j-1)) + w(i) conj(v(j-1)),  v(j-1) = 1
-            const T wl = conj_(tauj * ys[j - 1] + al);
-            for (int i = tid; i < j - 1; i += MTH) xn[i] = xn[i] - (vs[i] * wl + (tauj * ys[i] + al * vs[i]));
-        }
-        // ---- outputs of this step ----
-        if (w == j % P) {
-            const T sup = j < 32 ? Tr<T>::make(beta, 0.0) : Tr<T>::one();
-            for (int i = tid; i < j; i += MTH) A[(size_t)i + (size_t)j * lda] = (i < j - 1) ? vs[i] : sup;
-        }
-        if (w == 0 && tid == 0) { e[j - 1] = beta; tau[j - 1] = tauj; }
-        __syncthreads();
-        MSTAMP(6);
-        cur ^= 1;
-    }
-#undef MSTAMP
-#pragma unroll
-    for (int p = 0; p < PRL; ++p)
-#pragma unroll
-        for (int q = 0; q < PC; ++q) {
-            const int r = row_of(p), cc = tc + TCN * q;
-            if (r == cc && r < n) {
-                d[r] = real_(a[p][q]);
-                A[(size_t)r + (size_t)r * lda] = a[p][q];
-            }
-        }
-}
-// complex: 8 x 64 threads, 2 rows each (16 rows per workgroup), order <= 768;  real: 8 x 64 threads, 4 rows each (32 rows), <= 1024
-template <class T> constexpr int multi_trn() { return 8; }
-template <class T> constexpr int multi_prl() { return Tr<T>::cx ? 2 : 4; }
-template <class T> constexpr int multi_pc() { return Tr<T>::cx ? 12 : 16; }
-template <class T> constexpr int multi_rows() { return multi_trn<T>() * multi_prl<T>(); }
-template <class T> constexpr int multi_nmax() { return (MTH / multi_trn<T>()) * multi_pc<T>(); }
-
 template <class T> __global__ void __launch_bounds__(256) diag_extract_kernel(int n0, int n, const T* A, int lda, double* d) {
     int j = n0 + blockIdx.x * 256 + threadIdx.x;
     if (j < n) d[j] = real_(A[(size_t)j + (size_t)j * lda]);  // zhetrd_gpu.F90:89-94
@@ -1124,35 +872,19 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
     EIG_HIP(hipGetLastError());
 }
 
-// Order at which the blocked reduction stops and the register-resident kernels take over: option "trd_finish"
-//   -1 (default): the largest order the multi-workgroup kernel holds (768 complex / 1024 real) for a solve that has the device
-//      to itself, the largest the one-workgroup kernel holds (128 / 192) inside batch calls and lockstep groups (the chip is
-//      full of other solves there: a latency-bound column costs them nothing, P spinning workgroups would);
-//   32: the reference's cut-over with the LDS kernel hetd2_kernel (zhetrd_gpu.F90:84-87); values in between are allowed.
-template <class T> static int finish_order(const Ctx& c, int nprob) {
-    const bool multi_ok = nprob == 1 && !c.in_batch;
-    const int nmax = multi_ok ? multi_nmax<T>() : wide_nmax<T>();
+// Order at which the blocked reduction stops and the one-workgroup kernel takes over: option "trd_finish" (-1 = the largest
+// order hetd2_wide_kernel holds, 32 = the reference's cut-over with the LDS kernel hetd2_kernel; values in between are allowed).
+// (A multi-workgroup version of the register-resident finish -- up to 48 co-resident workgroups, one in-launch exchange per
+// column, order <= 768 / 1024 -- was built in round 4, is parity-green, and costs 6.8-8.2 us per column against the 8.5-9.3 of
+// the two-launch path: not kept.  profiles/r04_experiments.txt section 3, stamps in profiles/r04_multi_finish_stamps.txt.)
+template <class T> static int finish_order(const Ctx& c) {
+    const int nmax = wide_nmax<T>();
     if (c.trd_finish < 0) return nmax;
     return c.trd_finish <= TD ? TD : (c.trd_finish > nmax ? nmax : c.trd_finish);
 }
-constexpr int kTrdErrSlot = 12;   // c.d_info / c.h_info word: 1 = the multi-workgroup finish could not synchronise
-template <class T> static void launch_finish(Ctx& c, hipStream_t st, int nx, int n0, T* A, int lda, double* d, double* e, T* tau) {
-    if (nx <= TD) {
-        hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, A, lda, d, e, tau);
-    } else if (n0 <= wide_nmax<T>()) {
-        hipLaunchKernelGGL((hetd2_wide_kernel<T, wide_pc<T>()>), dim3(1), dim3(WTR * WTC), 0, st, n0, A, lda, d, e, tau);
-    } else {
-        constexpr int TRN = multi_trn<T>(), PRL = multi_prl<T>(), PC = multi_pc<T>(), NM = multi_nmax<T>();
-        const int P = (n0 + multi_rows<T>() - 1) / multi_rows<T>();          // <= 48 (complex) / 32 (real)
-        T* X = c.scratch<T>(Tr<T>::cx ? "trd_mXz" : "trd_mXd", 2 * (size_t)NM);
-        T* Y = c.scratch<T>(Tr<T>::cx ? "trd_mYz" : "trd_mYd", 2 * (size_t)NM);
-        unsigned* fl = c.scratch<unsigned>("trd_mflags", 2 * MULTI_PMAX);
-        EIG_HIP(hipMemsetAsync(fl, 0, sizeof(unsigned) * 2 * MULTI_PMAX, st));          // every polled word, before EVERY launch
-        EIG_HIP(hipMemsetAsync(c.d_info + kTrdErrSlot, 0, sizeof(int), st));
-        hipLaunchKernelGGL((hetd2_multi_kernel<T, TRN, PRL, PC>), dim3(P), dim3(MTH), 0, st, n0, P, A, lda, d, e, tau, X, Y, fl,
-                           c.d_info + kTrdErrSlot);
-        EIG_HIP(hipMemcpyAsync(c.h_info + kTrdErrSlot, c.d_info + kTrdErrSlot, sizeof(int), hipMemcpyDeviceToHost, st));
-    }
+template <class T> static void launch_finish(hipStream_t st, int nx, int n0, T* A, int lda, double* d, double* e, T* tau) {
+    if (nx <= TD) hipLaunchKernelGGL((hetd2_kernel<T>), dim3(1), dim3(256), 0, st, n0, A, lda, d, e, tau);
+    else hipLaunchKernelGGL((hetd2_wide_kernel<T, wide_pc<T>()>), dim3(1), dim3(WTR * WTC), 0, st, n0, A, lda, d, e, tau);
 }
 
 // nprob problems of order N reduced in lockstep: every per-column launch carries all of them (blockIdx.y); the trailing
@@ -1161,7 +893,7 @@ template <class T, int NB>
 static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdProb<T>* pr, int lda, int nb) {
     if (N <= 0) return;
     if (nb <= 0 || nb > NBMAX) nb = NBMAX;
-    const int nx = finish_order<T>(c, nprob);
+    const int nx = finish_order<T>(c);
     const int ldw = N;
     int np = N;
     auto trailing = [&](int npn, int nbn) {
@@ -1181,7 +913,7 @@ static void hetrd_lockstep(Ctx& c, hipStream_t st, int N, int nprob, const TrdPr
     }
     int n0 = N < nx ? N : nx;
     for (int q = 0; q < nprob; ++q) {
-        launch_finish<T>(c, st, nx, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);   // :86-87
+        launch_finish<T>(st, nx, n0, pr[q].A, lda, pr[q].d, pr[q].e, pr[q].tau);   // :86-87
         if (N > n0)
             hipLaunchKernelGGL((diag_extract_kernel<T>), dim3((N - n0 + 255) / 256), dim3(256), 0, st, n0, N, (const T*)pr[q].A, lda,
                                pr[q].d);
@@ -1193,7 +925,6 @@ template <class T>
 void hetrd_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, double* d, double* e, T* tau, T* W, int nb) {
     if (N <= 0) return;
     TrdProb<T> pr{A, d, e, tau, W, trd_scratch<T>(c, N)};
-    c.h_info[kTrdErrSlot] = 0;
     hetrd_lockstep<T, 1>(c, st, N, 1, &pr, lda, nb);
 }
 
@@ -1226,7 +957,7 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     EIG_HIP(hipMemcpyAsync(sc.xbuf, A, sizeof(T) * N, hipMemcpyDeviceToDevice, st));
     c.sync(st);
     *nlaunch = 0; *algo_bytes = 0.0;
-    const int nx = finish_order<T>(c, 1);
+    const int nx = finish_order<T>(c);
     int np = N;
     double* dsink = c.scratch<double>("sweep_d", (size_t)N + 8);
     TrdProb<T> pr{A, dsink, e, tau, W, sc};
@@ -1256,7 +987,6 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     EIG_HIP(hipGetLastError());
 }
 
-bool hetrd_failed(const Ctx& c) { return c.h_info[kTrdErrSlot] != 0; }
 template void hetrd_upper<double>(Ctx&, hipStream_t, int, double*, int, double*, double*, double*, double*, int);
 template void hetrd_upper<cplx>(Ctx&, hipStream_t, int, cplx*, int, double*, double*, cplx*, cplx*, int);
 template void hetrd_upper_batch<double>(Ctx&, hipStream_t, int, int, double* const*, int, double* const*, double* const*, double* const*,

@@ -318,15 +318,14 @@ def test_hetrd_vs_oracle(env, cplx, n, nb, fam):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("n,finish", [(33, -1), (100, -1), (128, -1), (129, -1), (192, -1), (193, -1), (200, 96), (411, -1), (411, 32), (411, 128),
-                                      (700, 64), (767, -1), (768, -1), (1024, -1), (1025, -1), (1300, -1), (1300, 300)])
+@pytest.mark.parametrize("n,finish", [(33, -1), (100, -1), (128, -1), (129, -1), (192, -1), (193, -1), (200, 96), (411, -1), (411, 32), (700, 64),
+                                      (1300, -1)])
 def test_hetrd_one_workgroup_finish(env, cplx, n, finish):
-    """Option trd_finish: the order at which the blocked reduction hands the rest of the matrix to the register-resident
-    kernels -- hetd2_multi_kernel (up to 48 co-resident workgroups, one in-launch exchange per column; order <= 768 complex /
-    1024 real; the default for a solve that has the device to itself), hetd2_wide_kernel (ONE workgroup, order <= 128 / 192;
-    batch calls), 32 = the reference's cut-over (zhetrd_gpu.F90:84-87 + zhetd2_gpu.F90).  d, e, tau and the reflectors must
-    agree with the reference-structured oracle exactly like the reference's own cut-over does -- incl. orders that fit a
-    kernel entirely, orders one above a capacity, and cut-overs in between."""
+    """Option trd_finish: the order at which the blocked reduction hands the rest of the matrix to ONE workgroup
+    (hetd2_wide_kernel: matrix in registers, order <= 128 complex / 192 real; 32 = the reference's cut-over,
+    zhetrd_gpu.F90:84-87 + zhetd2_gpu.F90).  d, e, tau and the reflectors must agree with the reference-structured oracle
+    exactly like the reference's own cut-over does -- incl. orders that fit the kernel entirely (n <= 128 / 192), orders one
+    above its capacity, and cut-overs in between."""
     torch, oracle, api = env
     A = oracle.gen_spd(n, 5000 + n, cplx, shift=float(n)) if n < 200 else oracle.gen_spd_fast(n, 5000 + n, cplx)
     Ao, do, eo, tauo = oracle.hetrd(np.triu(A), nb=32)
