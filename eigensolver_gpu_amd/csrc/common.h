@@ -109,6 +109,10 @@ constexpr int kTridiagDefault = 1;
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 3;
+// Panel width of the tridiagonalization: 32, the reference's own (zheevd_gpu.F90:63).  Rounds 1-3 used 64 (fewer, deeper rank-2nb
+// updates); with the round-4 mat-vec grid the narrower panel wins everywhere -- the per-column row kernel carries half the pending
+// columns: C3 trd 67.6 -> 66.6 ms, batch 17.66 -> 17.90 problems/s, C5 105.3 -> 109.9, C2 188.5 -> 194.0 (profiles/r04_experiments.txt 7).
+constexpr int kTrdNbDefault = 32;
 // Reduction to standard form: 0 symmetric recursion to 64x64 blocks, 1 two full triangular solves, 2 hybrid (symmetric
 // algorithm while the diagonal blocks are larger than gst_thr, two solves below); see hegst_upper in blas3.hip
 constexpr int kGstModeDefault = 2;
@@ -137,7 +141,7 @@ struct Ctx {
     double phase_ms[PH_COUNT] = {};
     int n_cu = 256;
     // tunables
-    int trd_nb = 64;
+    int trd_nb = kTrdNbDefault;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");

@@ -358,7 +358,7 @@ static const char* const kOptionNames[] = {"trd_nb", "bt_nb", "hemv_blocks", "re
                                            "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "tridiag", "tile_map",
                                            "trd_finish", "trace_marks"};
 bool apply_option(Ctx& c, const std::string& s, int value) {
-    if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? 64 : value; c.drop_graphs(); }
+    if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? kTrdNbDefault : value; c.drop_graphs(); }
     else if (s == "bt_nb") c.bt_nb = norm_bt_nb(value);
     else if (s == "hemv_blocks") { c.hemv_blocks = value < 0 ? 0 : (value > kHemvBlocksMax ? kHemvBlocksMax : value); c.drop_graphs(); }
     else if (s == "real_il_reference") c.real_il_reference = value > 0;

@@ -43,7 +43,7 @@ int eigsolve_set_host_threads(int nthreads);
  * TRIDIAG additionally accepts "host" / "device", POTRF "rec") when a context is created.  value <= 0 restores the default,
  * except where 0 is itself a setting (then value < 0 restores the default).
  *   "tridiag"   0 = host LAPACK dstedc exactly as the reference, 1 = device-side divide & conquer (default).
- *   "trd_nb"    panel width of the tridiagonalization, 1..64 (default 64; the caller's workspace contract bounds it).
+ *   "trd_nb"    panel width of the tridiagonalization, 1..64 (default 32 = the reference's, zheevd_gpu.F90:63; the caller's workspace contract bounds it).
  *   "trd_finish" order at which the blocked reduction hands the rest of the matrix to a one-workgroup kernel: -1 (default) =
  *               128 (complex) / 192 (real), the matrix then lives in the registers of one CU; 32 = the reference's cut-over
  *               (zhetrd_gpu.F90:84-87).
