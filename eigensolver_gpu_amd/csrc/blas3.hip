@@ -819,14 +819,15 @@ __global__ void __launch_bounds__(DGT) diag_block_kernel(int n_total, T* Umat, i
 // The diagonal block is factored IN PLACE by workgroup 0 while the other workgroups read the original block: workgroup 0
 // only stores U_kk once every other workgroup has announced (one agent-scope atomic on `loaded`, a cumulative counter
 // of the current factorization) that its copy sits in registers.  Nobody waits for workgroup 0, so the spin cannot deadlock.
-// (7 waves per SIMD = 72 VGPRs: the sixteen waves of a block-row workgroup then fit on a CU beside ONE 224-VGPR product workgroup
-// of the overlapped hegst chain instead of needing a completely empty CU -- potrf || hegst pipeline below)
+// (6 waves per SIMD = 80 VGPRs.  Round 3 forced 7 waves / 72 VGPRs so that the sixteen waves of a block-row workgroup fit on a CU
+// beside ONE 224-VGPR product workgroup of the overlapped hegst chain; the complex instantiation then spilled 8 bytes to scratch.
+// Re-measured in round 4: potrf || hegst 12.25 vs 12.26 ms, one stream 5.60 vs 5.62 -- no difference, no spill.)
 // up to four factorizations of one order side by side (blockIdx.y = problem: the lockstep groups of a batch call); every
 // problem has its own info word and its own announce counter
 constexpr int CHOL_MAXB = 4;
 template <class T> struct CholBatch { T* B[CHOL_MAXB]; };
 template <class T>
-__global__ void __launch_bounds__(DGT) __attribute__((amdgpu_waves_per_eu(7, 7)))
+__global__ void __launch_bounds__(DGT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 chol_row_kernel(int n_total, CholBatch<T> cb, int ldb, int k0, int* info0, unsigned* loaded0, unsigned expect) {
     __shared__ T rowb[2][DB];   // pivot row of the diagonal block
     __shared__ T rowp[2][DB];   // pivot row of this workgroup's chunk
