@@ -481,11 +481,11 @@ def main():
         g5 = gather_eigenvalues(res5, C5_PROBLEMS, m5)     # RCCL all_gather (the only collective; after the timing)
         # validity of one problem of this rank's share
         p_chk = mine5[-1]
-        Ap, Bp = gen_pair(n5, True, problem_seed(4, p_chk, 0), dev)
-        A2, B2 = Ap.clone(), Bp.clone()
+        Ap5, Bp5 = gen_pair(n5, True, problem_seed(4, p_chk, 0), dev)
+        A2, B2 = Ap5.clone(), Bp5.clone()
         wsc = workspace(0, n5)
         api.hegvdx(A2, B2, 1, m5, wsc)
-        rs5, be5, bo5 = check_solution(torch, Ap, Bp, wsc.Z, wsc.w[:m5], m5)
+        rs5, be5, bo5 = check_solution(torch, Ap5, Bp5, wsc.Z, wsc.w[:m5], m5)
         same = bool(torch.equal(wsc.w[:m5], res5[p_chk]))
         if rank == 0:
             out["c5"] = {"workload": "64 distinct zhegvdx N=%d eigenpairs 1..%d, p -> GPU (p mod %d), %d problems per solver call, "
@@ -497,7 +497,7 @@ def main():
                          "gathered_checksum": float(g5.sum()), "residual_checked_problem": rs5,
                          "residual_bound_N_eps": n5 * EPS, "b_orthonormality_checked_problem": bo5,
                          "rerun_bit_identical": same}
-        del st5, warm, Ap, Bp, A2, B2
+        del st5, warm, Ap5, Bp5, A2, B2
         torch.cuda.empty_cache()
 
     # ---- roofline legs (rank 0, on this rank's GPU after the timed region) -----------------------------------------

@@ -1394,6 +1394,32 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
 
 
+def test_bench_default_line_every_object(env):
+    """The driver's command (`python bench.py`, nothing switched off) at a small order: every object of the line is produced --
+    roofline, roofline_mfma, cpu_baseline, host_tridiag, c5 -- and the validity fields are judged next to their comparators
+    (residual_check = max(N eps, 4 x LAPACK's own residual on the SAME problem of the last timed step), strict_gate at N eps).
+    (Round 4: a name clash between the c5 object and the cpu_baseline leg broke exactly this path while every reduced
+    command line still passed.)"""
+    import json
+    import subprocess
+    import sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--order", "512", "--c5-order", "256", "--batch", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=envv)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("roofline", "roofline_mfma", "cpu_baseline", "host_tridiag", "c5", "residual_check", "strict_gate"):
+        assert d.get(key), key
+    assert d["n_gpus"] == 1 and d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    rc = d["residual_check"]
+    assert rc["pass"] is True and rc["residual_gpu_timed_solve"] <= rc["bound_max_N_eps_4x_lapack"]
+    assert d["strict_gate"]["pass"] is True
+    assert d["c5"]["rerun_bit_identical"] is True
+
+
 def test_bench_gpus_flag_starts_its_own_ranks(env):
     """`python bench.py --gpus 2` launched PLAINLY (no torchrun, no WORLD_SIZE): the script re-executes itself under
     torch.distributed.run with one rank per GPU (the flag used to be parsed and ignored, so a scaling run
