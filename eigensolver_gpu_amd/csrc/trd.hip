@@ -793,15 +793,15 @@ template <class T> __global__ void __launch_bounds__(256) diag_extract_kernel(in
 static int hemv_grid(const Ctx& c, int n) {
     int nt = (n + HT - 1) / HT;
     long ntiles = (long)nt * (nt + 1) / 2;
-    // Workgroup b takes tiles b, b+G, b+2G, ... with G = ONE workgroup per CU for a solve that has the device to itself: every
-    // workgroup streams through its tiles with the next tile's loads in flight while the finishing wave closes the current one
-    // (round 4: G = 256 against the two-per-CU grid of rounds 1-3: trd 68.0 -> 67.4 ms at C3, sweep 0.502 -> 0.509 of the HBM peak;
-    // G = 272 / 288 / 320 leave a ragged second round: 73-76 ms).  Inside a batch call four launch chains share the chip, and
-    // a mat-vec launch that asks for fewer CUs leaves the others' kernels more room: G = 3/4 of the CUs (192) gives the best
-    // batch rate (C3, 8 problems per call: 17.32 problems/s at 512, 17.65 at 256, 17.8 at 160 and 192, 17.41 at 96;
-    // profiles/r04_experiments.txt section 6) although one such chain alone would be slower (70.6 ms at 192).
+    // Workgroup b takes tiles b, b+G, b+2G, ... with G = ONE workgroup per CU: every workgroup streams through its tiles with the
+    // next tile's loads in flight while the finishing wave closes the current one (round 4: G = 256 against the two-per-CU grid of
+    // rounds 1-3: trd 68.0 -> 67.4 ms at C3, sweep 0.502 -> 0.509 of the HBM peak, batch rate 17.32 -> 17.65 problems/s; G = 272 /
+    // 288 / 320 leave a ragged second round: 73-76 ms).  Inside a batch call an even smaller grid would gain another 0.8 % (G = 192:
+    // 17.8 problems/s -- a launch that asks for fewer CUs leaves the other chains' kernels more room), but the per-workgroup
+    // partial sums of v^H A v are added up in grid order, so a grid that depends on the calling mode would cost the bit-identity of
+    // batch and single-problem results; one grid everywhere (profiles/r04_experiments.txt section 6).
     // (Spreading the tiles evenly over the minimum number of rounds was measured SLOWER in round 2.)
-    long cap = c.hemv_blocks > 0 ? c.hemv_blocks : (c.in_batch ? (3L * c.n_cu) / 4 : (long)c.n_cu);
+    long cap = c.hemv_blocks > 0 ? c.hemv_blocks : (long)c.n_cu;
     if (ntiles <= cap) return (int)ntiles;
     return (int)cap;
 }

@@ -1495,14 +1495,16 @@ def test_real_path_il_quirk_option(env):
 
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("workers,fuse", [(3, -1), (0, -1), (3, 2), (2, 4)])
-@pytest.mark.parametrize("n,m,nprob", [(130, 40, 2), (300, 75, 3), (97, 97, 5), (1100, 200, 2)])
+@pytest.mark.parametrize("n,m,nprob", [(130, 40, 2), (300, 75, 3), (97, 97, 5), (1100, 200, 2), (2100, 64, 2)])
 def test_batch_driver_bit_identical_to_single_solves(env, cplx, n, m, nprob, workers, fuse):
     """eigsolve_?hegvdx_batch / ?sygvdx_batch: nprob problems of one order in one call from one thread -- on the library's
     worker threads (default, `batch_workers` launch chains in flight, each an ordinary single solve on its own context), or,
     batch_workers = 0, on the caller's context with the tridiagonalizations in lockstep (every per-column launch carries
     all problems; 5 problems: more than one lockstep group), or the mixture the library picks for small orders
     (`batch_fuse` = g: every worker takes lockstep groups of g problems).  Eigenvalues, eigenvectors, the factor left in B
-    and the preserved strict lower triangle of A must be bit-identical to nprob calls of the single-problem driver."""
+    and the preserved strict lower triangle of A must be bit-identical to nprob calls of the single-problem driver (n = 2100: more
+    mat-vec tiles than workgroups -- the per-workgroup partial sums are added in grid order, so the grid must not depend on the
+    calling mode)."""
     torch, oracle, api = env
     assert api.set_option("batch_workers", workers) == 0 and api.set_option("batch_fuse", fuse) == 0
     probs = [(oracle.gen_spd_fast(n, 8800 + 31 * q + n, cplx), oracle.gen_spd_fast(n, 9900 + 37 * q + n, cplx, shift=float(n)))
