@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do an MFMA-bound product and the HBM-bound mat-vec of two different launch chains share the CUs?
 Two host threads, each with its own library context / stream: one loops over a product, the other over the mat-vec;
-times alone and together.  Usage: python tools/corun.py   (EIGSOLVE_GEMM_LDSPAD=8192 -> one product workgroup per CU)"""
+times alone and together.  Usage: python tools/corun.py"""
 import os
 import sys
 import threading
@@ -97,7 +97,6 @@ def run(fa, ra, fb, rb):
           (tt * 1e3, fa.__name__, out["a"] * 1e3, fb.__name__, out["b"] * 1e3, tt / (ta + tb)), flush=True)
 
 
-print("EIGSOLVE_GEMM_LDSPAD =", os.environ.get("EIGSOLVE_GEMM_LDSPAD", "0"))
 print("her2k n=4096 k=64 ('N','N' instantiation) beside hemv n=4096")
 run(her2k, 1000, mv, 4000)
 print("rank-64 update 'C','N' beside hemv")
