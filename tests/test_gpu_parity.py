@@ -1465,8 +1465,8 @@ def test_bench_eight_ranks_on_one_gpu(env):
     assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
     assert len(d["rank_elapsed_ms_min_max"]) == 2 and d["rank_elapsed_ms_min_max"][1] * 1e-3 * d["value"] <= 64.0 * 1.0001
     base[base.index("29541")] = "29542"
-    out = subprocess.run(base + ["--steps", "1", "--warmup", "1", "--order", "256", "--c5-order", "256"], capture_output=True, text=True,
-                         timeout=1200, env=envv)
+    out = subprocess.run(base + ["--steps", "1", "--warmup", "1", "--order", "256", "--c5-order", "256", "--batch", "4"], capture_output=True,
+                         text=True, timeout=1200, env=envv)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["config"]["problems_per_step_total"] == 32 and d["eigenvalues_gathered"] == [32, 64]
