@@ -1,4 +1,5 @@
 #!/bin/bash
+cd ${GRAFT_REPO_ROOT:-.}; timeout 1500 python -m pytest tests/test_gpu_parity.py -q -k "bench_eight or real_path_il or batch_driver_error or liwork or fortran_real or contexts_die or finalize" 2>&1 | tail -3
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
