@@ -39,26 +39,6 @@ __device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel
 #else
 #define TSTAMP(KID, PH, T0) do { } while (0)
 #endif
-#ifndef EIG_MV_NT
-#define EIG_MV_NT 0
-#endif
-// the matrix stream of the mat-vec: every element is read once per launch, by one CU
-typedef double mvd2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double stream_load(const double* p) {
-#if EIG_MV_NT
-    return __builtin_nontemporal_load(p);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ cplx stream_load(const cplx* p) {
-#if EIG_MV_NT
-    const mvd2 v = __builtin_nontemporal_load(reinterpret_cast<const mvd2*>(p));
-    return cplx{v.x, v.y};
-#else
-    return *p;
-#endif
-}
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
 constexpr int NBMAX = 64;  // maximum panel width
@@ -371,7 +351,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
             xr_raw = a.xbuf[min(r, max(nz - 1, 0))];
             const size_t roff = (size_t)min(r, n - 1);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) av[j] = stream_load(&a.A[roff + (size_t)min(c0 + wave * 16 + j, n - 1) * a.lda]);
+            for (int j = 0; j < 16; ++j) av[j] = a.A[roff + (size_t)min(c0 + wave * 16 + j, n - 1) * a.lda];
             __builtin_amdgcn_sched_barrier(0);
             xcs[slot][lane] = sel(c0 + lane < nz, xc_raw, zero);
         };
