@@ -5,7 +5,7 @@ import ctypes, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import eigensolver_gpu_amd.api as api
-api.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "_build", "libeigsolve_timing.so")
+# (build: make -C eigensolver_gpu_amd/csrc OUTDIR=../lib/v_timing EXTRA=-DEIG_TRD_TIMING=1; run with EIGSOLVE_GPU_LIB=.../lib/v_timing/libeigsolve_gpu.so)
 import torch
 
 def run(n, cx=True):
@@ -21,7 +21,7 @@ def run(n, cx=True):
     out1 = (ctypes.c_ulonglong * 36)()
     lib.eigsolve_debug_trd_timing(out1)
     d = [out1[i] - out0[i] for i in range(36)]
-    for k, name in ((0, "mv "), (1, "row"), (2, "col owner"), (3, "col offdiag")):
+    for k, name in ((0, "mv "), (1, "row")):
         cnt = d[k * 9]
         ph = [d[k * 9 + 1 + p] / max(cnt, 1) for p in range(8)]
         print("n=%5d %s launches=%5d  cumulative cycles at stamps: %s" % (n, name, cnt, " ".join("%7.0f" % x for x in ph)))
