@@ -98,7 +98,10 @@ template <class T> void potrf_upper_group(Ctx& c, hipStream_t st, int N, int npr
 // Triangular solves with the Cholesky factor (block offsets are multiples of 64 from U(0,0)), OUT OF PLACE: the result goes to
 // Y, X is used as workspace and destroyed (its blocks receive the updates of the substitution).  No staging copies: the
 // base-case products read X and write Y, the updates read Y and modify X.  X and Y must not overlap.
-template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y = U^-1 X
+// (rows_done, optional: called on the host right after the launches that make rows [r0, r0 + nr) of Y final have been queued on st,
+//  for the row blocks of recursion depth `hook_depth` -- lets the caller start consuming finished row blocks, e.g. the host copy)
+template <class T> void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64,
+                                 const std::function<void(int, int)>* rows_done = nullptr, int hook_depth = 0, int row0 = 0);  // Y = U^-1 X
 template <class T> void trsm_LUC(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y = U^-H X
 template <class T> void trsm_RUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base = 64);  // Y(mxn) = X U^-1
 // merged 256x256 inverse diagonal blocks for base = 256 (needs the 64-block inverses of potrf_upper / build_invU)

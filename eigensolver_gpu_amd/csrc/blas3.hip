@@ -1173,18 +1173,23 @@ template <class T> static Operand<T> op_invbase(Ctx& c, int base, int k0, int tr
 }
 
 template <class T>
-void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base) {
+void trsm_LUN(Ctx& c, hipStream_t st, int n, int m, const T* U, int ldu, int k0, T* X, int ldx, T* Y, int ldy, int base,
+              const std::function<void(int, int)>* rows_done, int hook_depth, int row0) {
     if (n <= 0 || m <= 0) return;
     base = norm_base(base);
     if (n <= base) {
         gemm<T>(c, st, n, m, n, Tr<T>::one(), op_invbase<T>(c, base, k0, 0, 0), opB('N', (const T*)X, ldx), Tr<T>::zero(), Y, ldy);
+        if (rows_done && hook_depth >= 0) (*rows_done)(row0, n);
         return;
     }
     int n1 = split_n1(n, base), n2 = n - n1;
-    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, Y + n1, ldy, base);                  // Y2 = U22^-1 X2
+    // (hook: a block at depth hook_depth reports as a whole; below that depth nothing reports)
+    const std::function<void(int, int)>* sub = (rows_done && hook_depth > 0) ? rows_done : nullptr;
+    trsm_LUN(c, st, n2, m, U, ldu, k0 + n1, X + n1, ldx, Y + n1, ldy, base, sub, hook_depth - 1, row0 + n1);   // Y2 = U22^-1 X2
     gemm<T>(c, st, n1, m, n2, Tr<T>::make(-1.0, 0.0), opA('N', U + (size_t)k0 + (size_t)(k0 + n1) * ldu, ldu),
             opB('N', (const T*)(Y + n1), ldy), Tr<T>::one(), X, ldx);                          // X1 -= U12 Y2
-    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx, Y, ldy, base);                                 // Y1 = U11^-1 X1
+    trsm_LUN(c, st, n1, m, U, ldu, k0, X, ldx, Y, ldy, base, sub, hook_depth - 1, row0);       // Y1 = U11^-1 X1
+    if (rows_done && hook_depth == 0) (*rows_done)(row0, n);
 }
 
 template <class T>
@@ -1573,7 +1578,8 @@ template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, con
                                   Epi, GemmBatch, int);                                                                  \
     template void potrf_upper<T>(Ctx&, hipStream_t, int, T*, int);                                                       \
     template void build_invU<T>(Ctx&, hipStream_t, int, const T*, int);                                                  \
-    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
+    template void trsm_LUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int,                    \
+                              const std::function<void(int, int)>*, int, int);                            \
     template void trsm_LUC<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
     template void trsm_RUN<T>(Ctx&, hipStream_t, int, int, const T*, int, int, T*, int, T*, int, int);                            \
     template void build_inv256<T>(Ctx&, hipStream_t, int, const T*, int);                                                \

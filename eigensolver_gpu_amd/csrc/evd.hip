@@ -456,14 +456,45 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
                              liwork);  // :163
     }
     if (info != 0) return -1;
+    // Many eigenvectors (full-spectrum C4: Z is 1 GB, 19 ms over PCIe after a 39 ms solve): the substitution finishes the row blocks
+    // of Z bottom-up, and the host copy of a finished block (a quarter of the rows) runs on the second stream beside the rest of the
+    // solve.  Only for a solve that has the device to itself; the solve itself is unchanged, results are bit-identical.
+    // (Splitting the COLUMNS instead changes the split-K decisions of the products, and at m = 1024 half-width solves lose what the
+    //  copy gains -- round 3.)
+    const bool zoverlap = !skip_host_copy && (long)N * m >= 4096L * 4096L && (c.overlap & 2) && !c.in_batch &&
+                          streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
+    bool copy_failed = false;
     {
         PhaseRange r(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167
         pt.begin(PH_TRSM);
-        trsm_LUN<T>(c, st, N, m, B, ldb, 0, Zs, N, Z, ldz, c.trsm_base);  // :169  Z = U^-1 Zs
+        if (!zoverlap) {
+            trsm_LUN<T>(c, st, N, m, B, ldb, 0, Zs, N, Z, ldz, c.trsm_base);  // :169  Z = U^-1 Zs
+        } else {
+            hipStream_t sc = c.second_stream();
+            int nev = 0;
+            const std::function<void(int, int)> rows_done = [&](int r0, int nr) {
+                hipEvent_t& ev = c.evStage[nev++ & 15];
+                if (!ev) EIG_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                EIG_HIP(hipEventRecord(ev, st));
+                EIG_HIP(hipStreamWaitEvent(sc, ev, 0));
+                if (hipMemcpy2DAsync(Z_h + r0, sizeof(T) * ldz_h, Z + r0, sizeof(T) * ldz, sizeof(T) * nr, m, hipMemcpyDeviceToHost, sc) !=
+                    hipSuccess)
+                    copy_failed = true;
+            };
+            trsm_LUN<T>(c, st, N, m, B, ldb, 0, Zs, N, Z, ldz, c.trsm_base, &rows_done, 2);
+            EIG_HIP(hipEventRecord(c.evB, sc));
+        }
         pt.end(PH_TRSM);
     }
-    pt.begin(PH_D2H);
-    if (!skip_host_copy) {
+    pt.begin(PH_D2H);   // (overlapped form: what is left of the copies after the solve)
+    if (zoverlap) {
+        EIG_HIP(hipStreamWaitEvent(st, c.evB, 0));
+        if (copy_failed) {
+            c.sync(st);
+            printf(" %s error: hipMemcpy2D failed!\n", name);
+            return -1;
+        }
+    } else if (!skip_host_copy) {
         hipError_t e = hipMemcpy2DAsync(Z_h, sizeof(T) * ldz_h, Z, sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) {
             printf(" %s error: hipMemcpy2D failed!\n", name);

@@ -800,11 +800,12 @@ def test_laxlib_call_pattern(env, cplx):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("opt,n,m", [("graph", 330, 80), ("overlap", 1300, 200), ("overlap", 2048, 64)])
+@pytest.mark.parametrize("opt,n,m", [("graph", 330, 80), ("overlap", 1300, 200), ("overlap", 2048, 64), ("overlap", 4160, 4160)])
 def test_optional_execution_modes_are_bit_identical(env, cplx, opt, n, m):
     """hipGraph replay and the two-chain pipeline (option "overlap": potrf's second half beside the part of hegst that only
     needs the first half of the factor, T factors beside the tridiagonal solver) only change HOW and WHEN the same kernels are
-    issued: bit-identical to the one-stream eager path.  n > gst_thr for "overlap": below that the pipeline does not apply."""
+    issued: bit-identical to the one-stream eager path.  n > gst_thr for "overlap": below that the pipeline does not apply;
+    m >= 4096: the final solve runs in column chunks with the host copy of a finished chunk beside the next one."""
     torch, oracle, api = env
     A = oracle.gen_spd_fast(n, 4000 + n, cplx)
     B = oracle.gen_spd_fast(n, 5000 + n, cplx, shift=float(n))
