@@ -35,7 +35,7 @@ namespace eig {
 #if EIG_TRD_TIMING
 __device__ unsigned long long g_trd_stamp[4][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
 __device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel, 1: panel_row_kernel
-#define TSTAMP(KID, PH, T0) do { if (blockIdx.x == (KID == 0 ? gg : 0) && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
+#define TSTAMP(KID, PH, T0) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
 #else
 #define TSTAMP(KID, PH, T0) do { } while (0)
 #endif
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #if EIG_TRD_TIMING
     const long long T0 = __builtin_readcyclecounter();
-    if (blockIdx.x == gg && threadIdx.x == 0) atomicAdd(&g_trd_count[0], 1ULL);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trd_count[0], 1ULL);
 #endif
     // Five waves: 0-3 stream and multiply the tiles, wave 4 evaluates the larfg scalars (a serial chain of ~1500 cycles)
     // while the first tile is being multiplied and finishes every tile (partial sums, S, the stored v) while the
@@ -322,8 +322,13 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     __shared__ T redt[2][64];
     __shared__ T xcs[3][HT];   // xh entries of the tile columns: tile k of this workgroup uses slot k % 3
     constexpr int NPL = 16;    // norm partials per lane loaded up front (N <= 4096 without the tail loop)
-    const bool is_gemv = (int)blockIdx.x < gg;
-    const int hb = (int)blockIdx.x - gg;  // hemv workgroup index
+    // The mat-vec workgroups come FIRST in the grid: tile t is then always taken by workgroup t mod gh, i.e. (gh = one per CU, a
+    // multiple of 8) by the same XCD in every column of the sweep, and what that XCD's L2 still holds of the tile from the previous
+    // column is a hit -- the whole stored triangle once it is below 8 x 4 MB (round 4: zhetrd N=2048 21.2 -> 20.2 ms, dsytrd
+    // N=2048 17.0 -> 16.8, zhetrd N=4096 66.6 -> 66.2; with the gemv workgroups in front the XCD of a tile moved with their count).
+    const bool is_gemv = (int)blockIdx.x >= a.gh;
+    const int hb = (int)blockIdx.x;          // hemv workgroup index
+    const int gb = (int)blockIdx.x - a.gh;   // gemv workgroup index
     if (is_gemv && wave == 4) return;
 
     // v = scale * xh + e_(n-1), xh = raw column with the entries >= nz zeroed.  Everything below is linear in
@@ -446,7 +451,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk), one item per wave
         const int npo = a.np - 1 - i;
         const int wbase = a.np - a.nb;
-        const int item = (int)blockIdx.x * 4 + wave;
+        const int item = gb * 4 + wave;
         if (item >= 2 * npo * a.nchunk) return;
         const int ch = item / (2 * npo);
         const int rem = item % (2 * npo);
