@@ -12,6 +12,10 @@
 #include "stedc.h"
 #include "trd.h"
 
+// smallest N*m for which the host copy of Z is issued block row by block row beside the final solve (hegvdx_core)
+#ifndef EIG_ZOVERLAP_MIN
+#define EIG_ZOVERLAP_MIN (2048L * 512L)
+#endif
 namespace eig {
 
 // ---- small kernels ---------------------------------------------------------------------------
@@ -456,12 +460,13 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
                              liwork);  // :163
     }
     if (info != 0) return -1;
-    // Many eigenvectors (full-spectrum C4: Z is 1 GB, 19 ms over PCIe after a 39 ms solve): the substitution finishes the row blocks
-    // of Z bottom-up, and the host copy of a finished block (a quarter of the rows) runs on the second stream beside the rest of the
-    // solve.  Only for a solve that has the device to itself; the solve itself is unchanged, results are bit-identical.
+    // The substitution finishes the row blocks of Z bottom-up, and the host copy of a finished block (a quarter of the rows) runs on
+    // the second stream beside the rest of the solve (full-spectrum C4: Z is 1 GB, 19 ms over PCIe after a 39 ms solve -> 4.7 ms
+    // exposed; C3: 1.19 -> 0.32 ms; below N*m = 2^20 the events cost what the copy gains).  Only for a solve that has the device
+    // to itself; the solve itself is unchanged, results are bit-identical.
     // (Splitting the COLUMNS instead changes the split-K decisions of the products, and at m = 1024 half-width solves lose what the
     //  copy gains -- round 3.)
-    const bool zoverlap = !skip_host_copy && (long)N * m >= 4096L * 4096L && (c.overlap & 2) && !c.in_batch &&
+    const bool zoverlap = !skip_host_copy && (long)N * m >= (long)EIG_ZOVERLAP_MIN && (c.overlap & 2) && !c.in_batch &&
                           streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
     bool copy_failed = false;
     {
