@@ -844,10 +844,11 @@ def test_pipelined_factorization_failure(env, cplx, bad):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("n,m", [(70, 20), (300, 77)])
+@pytest.mark.parametrize("n,m", [(70, 20), (300, 77), (1100, 1000)])
 def test_leading_dimensions_larger_than_n(env, cplx, n, m):
     """lda, ldb, ldz, ldz_h all different and > N (the reference takes them as separate arguments,
-    zhegvdx_gpu.F90:75-76); padding rows are poisoned and must come back untouched."""
+    zhegvdx_gpu.F90:75-76); padding rows are poisoned and must come back untouched.  (1100, 1000): N*m is large enough
+    for the host copy of Z to leave in row blocks beside the final solve (hegvdx_core).)"""
     torch, oracle, api = env
     lda, ldb, ldz, ldzh = n + 3, n + 8, n + 5, n + 2
     A = oracle.gen_spd(n, 6000 + n, cplx) if n < 100 else oracle.gen_spd_fast(n, 6000 + n, cplx)
