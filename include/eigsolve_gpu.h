@@ -59,7 +59,8 @@ int eigsolve_set_host_threads(int nthreads);
  *               block row), 0 the recursive form (no intra-grid dependency).
  *   "overlap"   bit mask of independent launch chains of one solve that run on a second stream (leased from the library's
  *               stream pool for the call): bit 0 = hegst beside the factorization, released stage by stage, bit 1 = larft T
- *               factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work).  Default 3.  Same
+ *               factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work) and, for N*m >= 2^20,
+ *               the host copy Z_h in row blocks beside the final triangular solve (zhegvdx_gpu.F90:169-180).  Default 3.  Same
  *               kernels, operands and order of operations per block: results are bit-identical to "overlap" 0.  Only applied
  *               to a solve that has the device to itself (best effort: no other call of this library in flight, not inside a
  *               batch call).
