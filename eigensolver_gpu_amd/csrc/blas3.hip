@@ -971,6 +971,338 @@ chol_row_kernel(int n_total, CholBatch<T> cb, int ldb, int k0, int* info0, unsig
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// chol_row2_kernel (round 5): the same block row -- U_kk = chol(B_kk), U(k, chunk c) = U_kk^-H B(k, chunk c), one workgroup per
+// 64-column chunk, every workgroup repeating the diagonal block -- with the elimination BLOCKED by 16 and everything but the
+// 16x16 diagonal blocks on MFMA.  chol_row_kernel walks 64 dependent elimination steps with sixteen waves and a workgroup
+// barrier per step (0.65 us per step, 42 us per block row, 2.7 ms of a C3 factorization with the chip idle); here a block row
+// is 4 panels, a panel = ONE wave factoring and inverting a 16x16 block (16 steps, no workgroup barrier inside) + two
+// barrier-separated MFMA stages for everybody.
+//
+// Layout.  The workgroup (4 waves) holds the TRANSPOSED block row L' = [B_kk | B_kc]^H (128 x 64: lower Cholesky L = U^H of the
+// diagonal block on top, the chunk below) in MFMA accumulator layout: wave w owns the 16-row blocks rb = w (diagonal part) and
+// rb = w + 4 (chunk part), four 16x16 column blocks each; lane l, component r of block (rb, cb) is
+// L'(16 rb + (l & 15), 16 cb + 4 r + (l >> 4)).  In this form an accumulator block IS the A fragment sequence of a product that
+// contracts over its column index (component r = k-step r), which is what both panel operations do:
+//     strip      L(rb, p)  =  A(rb, p) * conj(Linv_pp)^T        (A operand: the block itself, B operand: Linv_pp from LDS)
+//     trailing   A(rb, cb) -= L(rb, p) * L(cb, p)^H             (A operand: the strip block just formed, B operand: L(cb, p) from LDS)
+// so no accumulator ever goes through LDS to become an operand; only the three diagonal-part strip blocks and the 16x16 inverse
+// are published (2 workgroup barriers per panel, 8 per block row instead of 64).
+// The 16x16 factorization: Gaussian elimination on [A_pp | I] -> [L^H | L^-1], lane (i, g) = (l & 15, l >> 4) holding row i,
+// columns 4g..4g+3 of both halves; the pivot row and column travel through LDS inside the one wave (ds ops of a wave execute in
+// order: no barrier), pivots by Newton-refined v_rsq_f64 as in chol_row_kernel.
+// ------------------------------------------------------------------------------------------------
+#ifndef EIG_CHOL2_SKIP
+#define EIG_CHOL2_SKIP 0   // (timing variants: bit 0 no elimination, 1 no strip products, 2 no trailing products, 3 no stores, 4 no loads, 5 no announce)
+#endif
+constexpr int PW = 16;         // panel width of the blocked elimination
+constexpr int PLD = PW + 1;    // leading dimension of the 16x16 LDS blocks
+
+// c(m, n) +/-= sum_k a(m, k) conj(b(n, k)) for one 16x16x16 block: a = an accumulator block (component ks = k-step ks),
+// bf[ks][r] = b(4r + (lane & 3), 4ks + (lane >> 4))
+template <class T, bool NEG>
+__device__ __forceinline__ void mma16_conjb(double (&cr)[4], double (&ci)[4], const double (&xr)[4], const double (&xi)[4],
+                                            const T (&bf)[4][4]) {
+    constexpr bool CX = Tr<T>::cx;
+    constexpr int NG = NEG ? 1 : 0;
+    // (consecutive MFMAs write different accumulators: a dependent v_mfma_f64_4x4x4 waits for the whole pipeline)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cr[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(real_(bf[ks][r]), xr[ks], cr[r], 0, 0, NG);
+        if (CX) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ci[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(real_(bf[ks][r]), xi[ks], ci[r], 0, 0, NG);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cr[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(imag_(bf[ks][r]), xi[ks], cr[r], 0, 0, NG);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ci[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(imag_(bf[ks][r]), xr[ks], ci[r], 0, 0, 1 - NG);
+        }
+    }
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) chol_row2_kernel(int n_total, CholBatch<T> cb, int ldb, int k0, int* info0,
+                                                        unsigned* loaded0, unsigned expect) {
+    constexpr bool CX = Tr<T>::cx;
+    constexpr int BLK = PW * PLD;
+    __shared__ T s_A[BLK];            // diagonal 16x16 block: staging, then L^H (scaled rows)
+    __shared__ T s_I[3][BLK];         // L_pp^-1 (lower), [n][k]; slot p % 3 (the waves that run ahead / catch up still read older panels)
+    __shared__ T s_L[3][3][BLK];      // L(rb, p), rb = 1..3 of the diagonal part, [n][k]; slot p % 3
+    __shared__ T s_col[PW * PW];      // the pivot columns (unscaled) of the 16 elimination steps, [k][i]
+    __shared__ double s_piv[PW];      // l(i, i)
+    T* const Bm = cb.B[blockIdx.y];
+    int* const info = info0 + blockIdx.y;
+    unsigned* const loaded = loaded0 + blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.x;
+    const bool has_p = chunk > 0;
+    const int nb = min(DB, n_total - k0);
+    const int c0 = k0 + chunk * DB;
+    const int pc = min(DB, n_total - c0);
+    const int fm = lane & 15, fq = lane >> 4;
+    T* const Dblk = Bm + (size_t)k0 + (size_t)k0 * ldb;
+    T* const Pblk = Bm + (size_t)k0 + (size_t)c0 * ldb;
+
+    double ar_[2][4][4], ai_[2][4][4];
+    const int a_ = 16 * w + fm;                       // column of B inside the 64-block = row of L'
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b_ = 16 * q + 4 * r + fq;   // row of B inside the block row = column of L'
+                T v = Tr<T>::zero();
+                if (EIG_CHOL2_SKIP & 16) {
+                } else if (h == 0) {
+                    if (q <= w) {
+                        const T x = Dblk[(size_t)min(b_, nb - 1) + (size_t)min(a_, nb - 1) * ldb];
+                        const bool in = b_ <= a_ && a_ < nb;
+                        v = sel(in, conj_(x), sel(a_ == b_, Tr<T>::one(), Tr<T>::zero()));
+                        if (a_ == b_) v = Tr<T>::realpart(v);
+                    }
+                } else if (has_p) {
+                    const T x = Pblk[(size_t)min(b_, nb - 1) + (size_t)min(a_, pc - 1) * ldb];
+                    v = sel(b_ < nb && a_ < pc, conj_(x), Tr<T>::zero());
+                }
+                ar_[h][q][r] = real_(v);
+                ai_[h][q][r] = imag_(v);
+            }
+
+    auto frag = [&](const T* blk, T (&bf)[4][4]) {     // B fragments of a 16x16 LDS block [n][k]
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bf[ks][r] = blk[(4 * r + (lane & 3)) * PLD + 4 * ks + fq];
+    };
+    // block (h, P) <- block (h, P) * conj(Linv)^T
+    auto strip = [&](auto H_, auto P_, const T (&bI)[4][4]) {
+        constexpr int h = decltype(H_)::value, p = decltype(P_)::value;
+        if (EIG_CHOL2_SKIP & 2) return;
+        double xr[4] = {0.0, 0.0, 0.0, 0.0}, xi[4] = {0.0, 0.0, 0.0, 0.0};
+        mma16_conjb<T, false>(xr, xi, ar_[h][p], ai_[h][p], bI);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ar_[h][p][r] = xr[r]; ai_[h][p][r] = CX ? xi[r] : 0.0; }
+    };
+    // block (h, Q) -= block (h, P) * L(Q, P)^H
+    auto trail = [&](auto H_, auto Q_, auto P_, const T (&bL)[4][4]) {
+        constexpr int h = decltype(H_)::value, q = decltype(Q_)::value, p = decltype(P_)::value;
+        if (EIG_CHOL2_SKIP & 4) return;
+        mma16_conjb<T, true>(ar_[h][q], ai_[h][q], ar_[h][p], ai_[h][p], bL);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- the 16x16 diagonal block of panel p (one wave): A_pp -> L_pp (into the accumulator block), L_pp^-1 (into s_I) ----
+    auto factor = [&](auto P_) {
+        constexpr int p = decltype(P_)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_A[fm * PLD + 4 * r + fq] = Tr<T>::make(ar_[0][p][r], ai_[0][p][r]);
+        __builtin_amdgcn_wave_barrier();
+        const int i = fm, g = fq;
+        T left[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = 4 * g + c;
+            const T lo = s_A[i * PLD + j], up = s_A[j * PLD + i];
+            T v = sel(i >= j, lo, conj_(up));
+            if (i == j) v = Tr<T>::realpart(v);
+            left[c] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // Gaussian elimination on the (full, Hermitian) block, lane (i, g) = row i, columns 4g..4g+3.  Row k is NOT scaled when
+        // it becomes the pivot row: rows below take  row_i -= (a_ik / d) row_k  (one reciprocal on the chain), every row is
+        // scaled by its own 1 / sqrt(d_i) after the loop.  The pivot row is the conjugate of the pivot COLUMN (the Schur
+        // complement is Hermitian), so one LDS line per step carries everything, and the only thing the next pivot waits for is
+        // the next column: one multiply-add per lane, published before the other three are issued.  A bad pivot is recorded
+        // without a branch.  (First version: scaled pivot row, the inverse carried along as a right-hand side, per-value
+        // selects: 150 instructions + 18 wide LDS operations per step, 0.48 us per step -- one wave gets a fraction of the LDS
+        // rates, MI355X_MICROARCH.md "LDS".)
+        //
+        // L^-1 rides along as a second, independent dependency chain in the same loop (forward substitution, column j = l & 15 in
+        // all four 16-lane rows).  With c_k = the unscaled pivot column of step k (all 16 stay in LDS), l_ik = c_k[i] / sqrt(d_k),
+        // the substitution  x_i = -(sum_{k<i} l_ik x_k) / l_ii,  x_j = 1 / l_jj  becomes, for z_k = x_k / sqrt(d_k),
+        //     z_i = -(sum_{k<i} c_k[i] z_k) / d_i,   z_j = 1 / d_j      (x_k = 0 above the diagonal comes out by itself)
+        // -- only the reciprocal the elimination computes anyway; x_i = z_i sqrt(d_i) after the loop.  The four lanes of a column
+        // split the sum (lane row fq takes k = 4t + fq and keeps exactly those z_k) and add the partial sums with two half / row
+        // exchanges.  As a loop of its own behind the elimination this substitution cost as much as the elimination (two latency
+        // chains in a row); interleaved, each hides in the other's stalls.
+        double myd = 1.0;
+        int badk = PW;
+        T zq[4] = {Tr<T>::zero(), Tr<T>::zero(), Tr<T>::zero(), Tr<T>::zero()};
+        const int j = fm;
+        if (g == 0) s_col[i] = left[0];
+#pragma unroll
+        for (int k = 0; k < ((EIG_CHOL2_SKIP & 1) ? 0 : PW); ++k) {
+            T* const colk = s_col + k * PW;
+            // (substitution, row k: the columns it reads were published in earlier steps)
+            T sum = Tr<T>::zero();
+#pragma unroll
+            for (int t = 0; 4 * t < k; ++t)      // (columns k' >= k are not there yet: whatever the slot holds, possibly NaN, must not meet z = 0)
+                fma_(sum, sel(4 * t + fq < k, s_col[(4 * t + fq) * PW + k], Tr<T>::zero()), zq[t]);
+            __builtin_amdgcn_wave_barrier();
+            double d = real_(colk[k]);
+            const T ci_ = colk[i];
+            T cj[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cj[c] = conj_(colk[4 * g + c]);
+            __builtin_amdgcn_wave_barrier();
+            const bool ok = d > 0.0;
+            badk = (!ok && badk == PW) ? k : badk;
+            d = ok ? d : 1.0;
+            const double invd = fast_rcp(d);
+            const T f = sel(i > k, ci_ * invd, Tr<T>::zero());     // a(i, k) / d for the rows below the pivot row, else 0
+            const int k1 = k + 1, kc1 = k1 & 3;
+            if (k1 < PW) {
+                fms_(left[kc1], f, cj[kc1]);                                  // the next pivot column first ...
+                if (g == (k1 >> 2)) s_col[k1 * PW + i] = left[kc1];           // ... and published at once
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (!(k1 < PW && c == kc1)) fms_(left[c], f, cj[c]);
+            myd = (i == k) ? d : myd;
+            if (k > 0) {
+                T o = sum;
+                swap_halves(sum, o);
+                sum = sum + o;
+                o = sum;
+                swap_rows(sum, o);
+                sum = sum + o;
+            }
+            const T zk = (k == j) ? Tr<T>::make(invd, 0.0) : sum * (-invd);
+            zq[k >> 2] = sel((k & 3) == fq, zk, zq[k >> 2]);
+        }
+        if (badk < PW && lane == 0 && chunk == 0 && 16 * p + badk < nb) atomicCAS(info, 0, k0 + 16 * p + badk + 1);
+        {
+            const double ip = fast_rsqrt(myd);
+            double piv = myd * ip;
+            piv = fma(fma(-piv, piv, myd), 0.5 * ip, piv);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_A[i * PLD + 4 * g + c] = (4 * g + c == i) ? Tr<T>::make(piv, 0.0) : left[c] * ip;   // L^H(i, j), j >= i
+            if (g == 0) s_piv[i] = piv;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {               // L(m, n) = conj(L^H(n, m)), n <= m, back into the accumulator block
+            const int n = 4 * r + fq;
+            const T v = conj_(s_A[n * PLD + fm]);
+            ar_[0][p][r] = n <= fm ? real_(v) : 0.0;
+            ai_[0][p][r] = n <= fm ? imag_(v) : 0.0;
+        }
+        {
+            T* const sI = s_I[p % 3];               // L^-1(i, j) = z_i sqrt(d_i), rows i = 4t + fq of column j from this lane
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sI[(4 * t + fq) * PLD + j] = zq[t] * s_piv[4 * t + fq];
+        }
+    };
+
+    // One panel (p a compile-time constant: every accumulator index is static).  Only the diagonal part feeds the chain of
+    // factorizations; the schedule keeps everything else off it:
+    //  * wave p+1 runs AHEAD: as soon as its own strip block of column p exists it updates the next diagonal block (the only
+    //    operand is that block itself) and, after the barrier that publishes the strips, factors it while the other waves do the
+    //    panel's trailing products;
+    //  * the wave that has just factored (wave p) does all of its chunk-part work for panels p-1 (what it skipped while it was
+    //    factoring) and p AFTER that barrier, beside the next factorization -- nobody waits for it;
+    //  so a panel costs the chain: one 16x16 factorization + two block products + two barriers.  LDS blocks live in slot p % 3
+    //  (a wave that catches up reads panel p-1's inverse and strips while panel p+1's are being written).
+    auto panel = [&](auto P_) {
+        constexpr int p = decltype(P_)::value;
+        using PP = std::integral_constant<int, p>;
+        if (w == p) factor(PP{});
+        // (every load has landed = my copy of the diagonal part is in registers; free: three waves wait here for the first 16x16 block anyway)
+        if (p == 0 && has_p && !(EIG_CHOL2_SKIP & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                                   // B1(p): L_pp^-1 is in s_I[p % 3]
+        if (p == 0 && has_p && !(EIG_CHOL2_SKIP & 32) && tid == 0)
+            __hip_atomic_fetch_add(loaded, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {
+            T bI[4][4];
+            frag(s_I[p % 3], bI);
+            if (w > p) {
+                strip(I0{}, PP{}, bI);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_L[p % 3][w - 1][fm * PLD + 4 * r + fq] = Tr<T>::make(ar_[0][p][r], ai_[0][p][r]);
+            }
+            if constexpr (p < 3) {
+                if (w == p + 1) {
+                    __builtin_amdgcn_wave_barrier();
+                    T bL[4][4];
+                    frag(s_L[p % 3][p], bL);
+                    trail(I0{}, std::integral_constant<int, p + 1>{}, PP{}, bL);
+                }
+            }
+            if (has_p && w != p + 1 && w != p) strip(I1{}, PP{}, bI);
+        }
+        __syncthreads();                                                                   // B2(p): the strips of column p are in s_L[p % 3]
+        if (w == p) {
+            if (has_p) {
+                T bI[4][4], bL[4][4];
+                if constexpr (p > 0) {       // panel p-1, skipped while this wave was factoring: the chunk-part blocks
+                    using PM = std::integral_constant<int, p - 1>;
+                    frag(s_I[(p - 1) % 3], bI);
+                    strip(I1{}, PM{}, bI);
+                    frag(s_L[(p - 1) % 3][p - 1], bL); trail(I1{}, PP{}, PM{}, bL);
+                    if constexpr (p + 1 < 4) { frag(s_L[(p - 1) % 3][p], bL); trail(I1{}, std::integral_constant<int, p + 1>{}, PM{}, bL); }
+                    if constexpr (p + 2 < 4) { frag(s_L[(p - 1) % 3][p + 1], bL); trail(I1{}, std::integral_constant<int, p + 2>{}, PM{}, bL); }
+                }
+                frag(s_I[p % 3], bI);
+                strip(I1{}, PP{}, bI);
+                if constexpr (p + 1 < 4) { frag(s_L[p % 3][p], bL); trail(I1{}, std::integral_constant<int, p + 1>{}, PP{}, bL); }
+                if constexpr (p + 2 < 4) { frag(s_L[p % 3][p + 1], bL); trail(I1{}, std::integral_constant<int, p + 2>{}, PP{}, bL); }
+                if constexpr (p + 3 < 4) { frag(s_L[p % 3][p + 2], bL); trail(I1{}, std::integral_constant<int, p + 3>{}, PP{}, bL); }
+            }
+        } else if (w != p + 1) {
+            T bL[4][4];
+            if constexpr (p + 1 < 4) {
+                using Q = std::integral_constant<int, p + 1>;
+                frag(s_L[p % 3][p], bL);
+                if (w >= p + 1) trail(I0{}, Q{}, PP{}, bL);
+                if (has_p) trail(I1{}, Q{}, PP{}, bL);
+            }
+            if constexpr (p + 2 < 4) {
+                using Q = std::integral_constant<int, p + 2>;
+                frag(s_L[p % 3][p + 1], bL);
+                if (w >= p + 2) trail(I0{}, Q{}, PP{}, bL);
+                if (has_p) trail(I1{}, Q{}, PP{}, bL);
+            }
+            if constexpr (p + 3 < 4) {
+                using Q = std::integral_constant<int, p + 3>;
+                frag(s_L[p % 3][p + 2], bL);
+                if (w >= p + 3) trail(I0{}, Q{}, PP{}, bL);
+                if (has_p) trail(I1{}, Q{}, PP{}, bL);
+            }
+        }
+    };
+    panel(std::integral_constant<int, 0>{});
+    panel(std::integral_constant<int, 1>{});
+    panel(std::integral_constant<int, 2>{});
+    panel(std::integral_constant<int, 3>{});
+
+    if (!has_p && !(EIG_CHOL2_SKIP & 32)) {
+        if (tid == 0) {      // (bounded spin, see chol_row_kernel)
+            long spins = 0;
+            while ((int)(__hip_atomic_load(loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expect) < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1L << 22)) { atomicCAS(info, 0, -4096 - k0); break; }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b_ = 16 * q + 4 * r + fq;
+            if (EIG_CHOL2_SKIP & 8) {
+            } else if (!has_p) {
+                if (q <= w && b_ <= a_ && a_ < nb)
+                    Dblk[(size_t)b_ + (size_t)a_ * ldb] = conj_(Tr<T>::make(ar_[0][q][r], ai_[0][q][r]));
+            } else {
+                if (b_ < nb && a_ < pc) Pblk[(size_t)b_ + (size_t)a_ * ldb] = conj_(Tr<T>::make(ar_[1][q][r], ai_[1][q][r]));
+            }
+        }
+}
+
 // A_kk <- invU^H * Herm(A_kk) * invU for one diagonal block (upper triangle in/out, real diagonal).
 template <class T>
 __global__ void __launch_bounds__(256) hegs2_block_kernel(int nb, T* Ablk, int lda, const T* inv) {
@@ -1271,6 +1603,48 @@ static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const*
                              int* info0, unsigned* loaded0) {
     CholBatch<T> cb;
     for (int q = 0; q < CHOL_MAXB; ++q) cb.B[q] = B[q < nprob ? q : 0];
+    if (c.potrf_mode >= 2) {
+        // Round 5: block rows in PAIRS.  Per pair: block row k (chol_row2_kernel), the rank-64 update of block row k+1 alone (a
+        // 64 x rem product: <= 252 small tiles), block row k+1, then ONE rank-128 update of everything below the pair -- half the
+        // passes over the trailing matrix at twice the K (the engine does 47 instead of 34 TFLOP/s there).
+        Epi e; e.uplo = 1; e.herm_diag = 1;
+        for (int kb = kb0; kb < kb1; kb += 2) {
+            const int k0 = kb * DB;
+            const int nb = min(DB, N - k0), rem = N - k0 - nb;
+            int chunks = (rem + DB - 1) / DB;
+            expect += (unsigned)chunks;
+            hipLaunchKernelGGL((chol_row2_kernel<T>), dim3(1 + chunks, nprob), dim3(256), 0, st, N, cb, ldb, k0, info0, loaded0, expect);
+            if (rem <= 0) break;
+            const int k1 = k0 + nb;
+            if (kb + 1 >= kb1) {       // (odd number of block rows in this range: plain rank-64 update)
+                for (int q = 0; q < nprob; ++q) {
+                    const T* B12 = B[q] + (size_t)k0 + (size_t)k1 * ldb;
+                    gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
+                            B[q] + (size_t)k1 + (size_t)k1 * ldb, ldb, e);
+                }
+                break;
+            }
+            const int nb1 = min(DB, rem), rem1 = rem - nb1;
+            for (int q = 0; q < nprob; ++q) {
+                const T* B12 = B[q] + (size_t)k0 + (size_t)k1 * ldb;
+                gemm<T>(c, st, nb1, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
+                        B[q] + (size_t)k1 + (size_t)k1 * ldb, ldb, e);
+            }
+            chunks = (rem1 + DB - 1) / DB;
+            expect += (unsigned)chunks;
+            hipLaunchKernelGGL((chol_row2_kernel<T>), dim3(1 + chunks, nprob), dim3(256), 0, st, N, cb, ldb, k1, info0, loaded0, expect);
+            if (rem1 > 0) {
+                const int k2 = k1 + nb1;
+                for (int q = 0; q < nprob; ++q) {
+                    const T* B13 = B[q] + (size_t)k0 + (size_t)k2 * ldb;
+                    gemm<T>(c, st, rem1, rem1, nb + nb1, Tr<T>::make(-1.0, 0.0), opA('C', B13, ldb), opB('N', B13, ldb), Tr<T>::one(),
+                            B[q] + (size_t)k2 + (size_t)k2 * ldb, ldb, e);
+                }
+            }
+        }
+        EIG_HIP(hipGetLastError());
+        return;
+    }
     for (int kb = kb0; kb < kb1; ++kb) {
         const int k0 = kb * DB;
         const int nb = min(DB, N - k0), rem = N - k0 - nb;

@@ -45,6 +45,12 @@ __host__ __device__ inline void fma_(cplx& a, cplx b, cplx c) {
     a.x = fma(b.x, c.x, a.x); a.x = fma(-b.y, c.y, a.x);
     a.y = fma(b.x, c.y, a.y); a.y = fma(b.y, c.x, a.y);
 }
+// a -= b*c
+__host__ __device__ inline void fms_(double& a, double b, double c) { a = fma(-b, c, a); }
+__host__ __device__ inline void fms_(cplx& a, cplx b, cplx c) {
+    a.x = fma(-b.x, c.x, a.x); a.x = fma(b.y, c.y, a.x);
+    a.y = fma(-b.x, c.y, a.y); a.y = fma(-b.y, c.x, a.y);
+}
 // a -= conj(b)*c
 __host__ __device__ inline void fmsc_(double& a, double b, double c) { a = fma(-b, c, a); }
 __host__ __device__ inline void fmsc_(cplx& a, cplx b, cplx c) {
@@ -109,6 +115,7 @@ constexpr int kTridiagDefault = 1;
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 3;
+constexpr int kPotrfDefault = 2;
 // Panel width of the tridiagonalization: 32, the reference's own (zheevd_gpu.F90:63).  Rounds 1-3 used 64 (fewer, deeper rank-2nb
 // updates); with the round-4 mat-vec grid the narrower panel wins everywhere -- the per-column row kernel carries half the pending
 // columns: C3 trd 67.6 -> 66.6 ms, batch 17.66 -> 17.90 problems/s, C5 105.3 -> 109.9, C2 188.5 -> 194.0 (profiles/r04_experiments.txt 7).
@@ -159,7 +166,8 @@ struct Ctx {
     };
     std::map<std::string, GraphEntry> graphs;
     int trsm_base = kTrsmBaseDefault;
-    int potrf_mode = 1;      // 1: right-looking block rows (chol_row_kernel + a rank-64 update each), 0: recursive (potrf_rec)
+    int potrf_mode = kPotrfDefault;   // 2: right-looking block rows in pairs (chol_row2_kernel: elimination blocked by 16 on MFMA; rank-128
+                             // trailing updates), 1: the round-2 form (chol_row_kernel + a rank-64 update per block row), 0: recursive (potrf_rec)
     int gst_mode = kGstModeDefault;
     int gst_thr = kGstThrDefault;
     int real_il_reference = 0;  // 1: real path copies eigenvectors 1..m whatever il is, like dsyevd_gpu.F90:108

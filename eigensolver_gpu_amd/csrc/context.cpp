@@ -365,7 +365,7 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "graph") c.use_graph = value > 0;
     else if (s == "overlap") c.overlap = value < 0 ? kOverlapDefault : (value & 3);
     else if (s == "trsm_base") c.trsm_base = value <= 0 ? kTrsmBaseDefault : norm_trsm_base(value);
-    else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : 1;
+    else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : (value == 1 ? 1 : kPotrfDefault);
     else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? kGstModeDefault : value;
     else if (s == "gst_thr") c.gst_thr = value <= 0 ? kGstThrDefault : (value < 256 ? 256 : value);
     else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;

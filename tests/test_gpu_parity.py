@@ -155,9 +155,10 @@ def test_her2k_vs_numpy(env, cplx, n, k):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("n", [1, 2, 31, 64, 65, 129, 300])
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [2, 1, 0])
 def test_potrf_and_trsm_vs_oracle(env, cplx, n, mode):
-    """mode 1: right-looking block rows (chol_row_kernel, default); mode 0: the recursive form."""
+    """mode 2: block rows in pairs, elimination blocked by 16 on MFMA (chol_row2_kernel, default); mode 1: the round-2
+    block-row kernel (chol_row_kernel, rank-64 updates); mode 0: the recursive form."""
     torch, oracle, api = env
     B = oracle.gen_spd(n, 2000 + n, cplx, shift=float(n))
     Bin = np.triu(B).copy()
@@ -167,7 +168,7 @@ def test_potrf_and_trsm_vs_oracle(env, cplx, n, mode):
         assert api.set_option("potrf", mode) == 0
         assert api.potrf(Bd) == 0
     finally:
-        api.set_option("potrf", 1)
+        api.set_option("potrf", -1)
     Uo, io = oracle.potrf_upper(B)
     assert io == 0
     assert rel(np.triu(api.to_host(Bd)), np.triu(Uo)) <= 100 * n * EPS
@@ -179,14 +180,20 @@ def test_potrf_and_trsm_vs_oracle(env, cplx, n, mode):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-def test_potrf_reports_first_bad_pivot(env, cplx):
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("bad", [100, 0, 63, 64, 149])
+def test_potrf_reports_first_bad_pivot(env, cplx, mode, bad):
     torch, oracle, api = env
     n = 150
     B = oracle.gen_spd(n, 7, cplx, shift=float(n))
-    B[100, 100] = -5.0
-    info = api.potrf(api.to_device(np.triu(B)))
+    B[bad, bad] = -5.0
+    try:
+        api.set_option("potrf", mode)
+        info = api.potrf(api.to_device(np.triu(B)))
+    finally:
+        api.set_option("potrf", -1)
     _, io = oracle.potrf_upper(B)
-    assert info == io == 101
+    assert info == io == bad + 1
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -241,17 +248,23 @@ def test_potrf_block_rows_under_concurrent_load(env):
 
 
 @pytest.mark.parametrize("cplx", [False, True])
-@pytest.mark.parametrize("n", [777, 1100])
-def test_potrf_block_rows_larger(env, cplx, n):
-    """Right-looking block-row Cholesky on orders with many block rows and a ragged last block: factor against LAPACK
-    (numpy), on the reference recipe (ill-conditioned) by backward error ||U^H U - B|| / ||B||."""
+@pytest.mark.parametrize("n", [777, 1100, 1216])
+@pytest.mark.parametrize("mode", [2, 1])
+def test_potrf_block_rows_larger(env, cplx, n, mode):
+    """Right-looking block-row Cholesky (both block-row kernels) on orders with many block rows -- an odd and an even number of
+    them, ragged and full last blocks: factor against LAPACK (numpy), on the reference recipe (ill-conditioned) by backward error
+    ||U^H U - B|| / ||B||."""
     torch, oracle, api = env
     for shift in (float(n), 0.0):
         B = oracle.gen_spd_fast(n, 2300 + n, cplx, shift=shift)
         Bin = np.triu(B).copy()
         Bin[np.tril_indices(n, -1)] = 2.5
         Bd = api.to_device(Bin)
-        assert api.potrf(Bd) == 0
+        try:
+            api.set_option("potrf", mode)
+            assert api.potrf(Bd) == 0
+        finally:
+            api.set_option("potrf", -1)
         got = api.to_host(Bd)
         assert np.all(got[np.tril_indices(n, -1)] == 2.5)
         U = np.triu(got)
@@ -685,7 +698,7 @@ def test_algorithm_options_agree(env, cplx):
                           ("bt64", {"bt_nb": 64}), ("bt128", {"bt_nb": 128}), ("bt512", {"bt_nb": 512}), ("tb64", {"trsm_base": 64}),
                           ("tb256_gst2", {"trsm_base": 256, "gst": 2, "gst_thr": 256}),
                           ("tb512", {"trsm_base": 512}), ("tb1024_gst2", {"trsm_base": 1024, "gst": 2, "gst_thr": 256}),
-                          ("potrf_rec", {"potrf": 0})):
+                          ("potrf_rec", {"potrf": 0}), ("potrf_r2", {"potrf": 1})):
             for k, v in opts.items():
                 assert api.set_option(k, v) == 0
             info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
@@ -693,11 +706,11 @@ def test_algorithm_options_agree(env, cplx):
             assert oracle.residual(A, B, w, Z) <= n * EPS
             res[key] = (w, Z)
             for k in opts:
-                api.set_option(k, -1 if k == "gst" else (1 if k == "potrf" else 0))
+                api.set_option(k, -1 if k in ("gst", "potrf") else 0)
     finally:
         for k in ("gst", "gst_thr", "bt_nb", "trsm_base"):
             api.set_option(k, -1 if k == "gst" else 0)
-        api.set_option("potrf", 1)
+        api.set_option("potrf", -1)
     w0, Z0 = res["default"]
     for key, (w, Z) in res.items():
         assert oracle.compare_1d(w0, w)[0] <= 1e-13, key
