@@ -25,6 +25,36 @@ def host_threads_per_rank(cores, world):
     return max(1, min(64, int(cores) // max(int(world), 1)))
 
 
+def rank_cpu_slice(cpus, local_rank, local_world):
+    """The CPUs local rank `local_rank` of `local_world` ranks on one node may use: a contiguous, equal share of the sorted
+    list `cpus` (the process' current affinity mask), disjoint from every other rank's.  A rank drives its GPU from a handful
+    of host threads (the caller, the library's batch workers, the divide & conquer's deflation scans, OpenBLAS for the host
+    tridiagonal option): eight unpinned ranks would migrate over all 256 cores of the node and share caches at random."""
+    cpus = sorted(int(c) for c in cpus)
+    local_world = max(1, int(local_world))
+    local_rank = int(local_rank) % local_world
+    per = len(cpus) // local_world
+    if per < 1:                      # fewer CPUs than ranks: everybody keeps the whole mask
+        return cpus
+    return cpus[local_rank * per:(local_rank + 1) * per]
+
+
+def pin_rank_to_cpu_slice(local_rank, local_world):
+    """Restricts this process (and every thread it starts afterwards: the library's workers inherit the mask) to its
+    rank_cpu_slice.  Call before the library creates its worker threads.  Returns the CPU list now in force; a platform
+    without sched_setaffinity, or a refusal by the OS, leaves the mask alone and returns it."""
+    import os
+    if not hasattr(os, "sched_getaffinity"):
+        return list(range(os.cpu_count() or 1))
+    cur = sorted(os.sched_getaffinity(0))
+    want = rank_cpu_slice(cur, local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError:
+        return cur
+    return sorted(os.sched_getaffinity(0))
+
+
 class InflightPool:
     """`nthr` persistent worker threads.  `init(t)` runs once in worker t (device selection, solver options: the
     library's options are per context, i.e. per thread); `map(fn, items)` hands items[t::nthr] to worker t, which
@@ -129,7 +159,7 @@ def gather_eigenvalues(local, n_problems, m):
     for k, (p, wv) in enumerate(sorted(local.items())):
         buf[k, 0] = float(p)
         buf[k, 1:] = wv[:m].to(torch.float64)
-    if world > 1:
+    if dist.is_initialized():       # (also with ONE rank: the collective then runs over the process group's backend all the same)
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)
     else:
@@ -141,4 +171,40 @@ def gather_eigenvalues(local, n_problems, m):
         ids = part[:, 0].to(torch.int64)
         keep = ids >= 0
         out[ids[keep]] = part[keep, 1:]
+    return out
+
+
+def gather_eigenvectors(local, n_problems, n, m):
+    """Optional gather of the eigenvector blocks ("w ... and optionally Z(1:N,1:m)"), off by default in
+    bench.py (--gather-z): local = {problem_id: Z} with Z the solver's output block in its device layout -- a tensor whose first
+    m rows are the m eigenvectors (column-major N x m = row-major m x N) -- -> [n_problems, m, n] on rank 0 (None elsewhere).
+    One all_gather of this rank's padded [per, m, n] block plus one of the problem ids; this is the only place the batch path
+    moves bulk data between GPUs (C5: 64 x 512 x 2048 complex = 1 GiB in all, 128 MiB per rank over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    per = (n_problems + world - 1) // world
+    any_t = next(iter(local.values())) if local else torch.zeros((m, n), dtype=torch.float64)
+    buf = torch.zeros((per, m, n), dtype=any_t.dtype, device=any_t.device)
+    ids = torch.full((per,), -1, dtype=torch.int64, device=any_t.device)
+    for k, (p, Z) in enumerate(sorted(local.items())):
+        ids[k] = p
+        buf[k] = Z[:m, :n]
+    if dist.is_initialized():
+        idl = [torch.empty_like(ids) for _ in range(world)]
+        dist.all_gather(idl, ids)
+        # (complex blocks travel as (re, im) pairs: every backend moves real tensors)
+        sbuf = torch.view_as_real(buf) if buf.is_complex() else buf
+        rparts = [torch.empty_like(sbuf) for _ in range(world)]
+        dist.all_gather(rparts, sbuf)
+        parts = [torch.view_as_complex(x) if buf.is_complex() else x for x in rparts]
+    else:
+        parts, idl = [buf], [ids]
+    if rank != 0:
+        return None
+    out = torch.zeros((n_problems, m, n), dtype=any_t.dtype, device=any_t.device)
+    for part, pid in zip(parts, idl):
+        keep = pid >= 0
+        out[pid[keep]] = part[keep]
     return out

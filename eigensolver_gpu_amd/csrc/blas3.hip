@@ -1839,6 +1839,43 @@ template <class T>
 static void hegst_hybrid(Ctx& c, hipStream_t st, int n, int k0, T* A, int lda, const T* U, int ldu, int thr, UGate* gate = nullptr);
 template <class T> static void hegst_blocked(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu);
 
+
+// Largest sizes the scratch slots of hegst take inside the hybrid recursion, allocated BEFORE anything of hegst is queued: a slot
+// that grows inside the recursion synchronises the context's streams (Ctx::scratch_bytes) -- the potrf || hegst pipeline then
+// loses its overlap on the first solve of a size.  Block steps: n1 = split_n1(n, gran) rounds UP, so T / Xh are n1 x (n - n1) and H
+// is n1 x n1 with n1 possibly above n / 2 (N = 1300, gran 256: n1 = 768); two-solve leaves: F, G of the largest leaf order.
+template <class T> static void hegst_pregrow(Ctx& c, int N) {
+    if (N <= 1) return;
+    const int gran = norm_base(c.trsm_base), thr = c.gst_thr;
+    size_t qT = 64, qH = 64, qF = 64;
+    if (c.gst_mode == 2 && N > thr && N >= 256) {
+        std::function<void(int)> walk = [&](int n) {
+            if (n <= thr || n <= gran) { qF = std::max(qF, (size_t)n * n); return; }
+            const int n1 = split_n1(n, gran), n2 = n - n1;
+            qT = std::max(qT, (size_t)n1 * n2);
+            qH = std::max(qH, (size_t)n1 * n1);
+            walk(n1);
+            walk(n2);
+        };
+        walk(N);
+    } else if (c.gst_mode == 3 && N >= 256) {
+        const int nb = gran < 256 ? 256 : gran;
+        qT = (size_t)nb * N; qH = (size_t)nb * nb; qF = (size_t)nb * nb;
+    } else if (c.gst_mode == 0 || N < 256) {
+        const int n1 = split_n1(N);
+        qT = (size_t)n1 * (N - n1) + 64; qH = (size_t)n1 * n1;
+    } else {
+        qF = (size_t)N * N;
+    }
+    (void)c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", qT);
+    (void)c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", qT);
+    (void)c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", qH);
+    if (qF > 64) {
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", qF);
+        (void)c.scratch<T>(Tr<T>::cx ? "gst_Gz" : "gst_Gd", qF);
+    }
+}
+
 template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
     // option "gst": 0 = symmetric recursion down to 64x64 blocks (~16N/64 small launches),
     //               1 = two full triangular solves (N^3 multiply-adds, ~4N/64 large launches),
@@ -1847,13 +1884,7 @@ template <class T> void hegst_upper(Ctx& c, hipStream_t st, int N, T* A, int lda
     //                   <= "gst_thr" (1024),
     //               3 = the reference's loop with nb = the order of the inverse diagonal blocks.
     const int mode = c.gst_mode, thr = c.gst_thr;
-    // (grow the scratch slots of the block steps to their largest size up front: the recursion asks for the small ones first)
-    if (N > 1) {
-        const size_t q = (size_t)N * N / 4 + 64;
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", q);
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", q);
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", q);
-    }
+    hegst_pregrow<T>(c, N);   // (the recursion asks for the small blocks first)
     if (N < 256 || mode == 0) hegst_rec(c, st, N, 0, A, lda, U, ldu);
     else if (mode == 3) hegst_blocked(c, st, N, A, lda, U, ldu);
     else if (mode == 1 || N <= thr) hegst_two_solves(c, st, N, A, lda, U, ldu);
@@ -1927,12 +1958,7 @@ template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda
     }
     // (everything above is queued before the first wait below is: a wait on an event that has not been recorded yet is a no-op)
     hipStream_t s2 = c.second_stream();
-    {   // the block steps' scratch at its largest size before anything of hegst is queued (the recursion asks for the small ones first)
-        const size_t q = (size_t)N * N / 4 + 64;
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Tz" : "gst_Td", q);
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Xz" : "gst_Xd", q);
-        (void)c.scratch<T>(Tr<T>::cx ? "gst_Hz" : "gst_Hd", q);
-    }
+    hegst_pregrow<T>(c, N);
     UGate gate{s2, c.evStage, 0};
     hegst_hybrid<T>(c, s2, N, 0, A, lda, (const T*)B, ldb, c.gst_thr, &gate);
     EIG_HIP(hipEventRecord(c.evB, s2));

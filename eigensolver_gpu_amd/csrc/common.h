@@ -116,6 +116,10 @@ constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
 constexpr int kOverlapDefault = 3;
 constexpr int kPotrfDefault = 2;
+// Largest library-side copy of the standard problem's eigenvectors (N x m, MiB) the generalized drivers allocate; beyond it (or when
+// that much device memory is not available) the vectors are formed in the caller's Z and the final triangular solve runs in column
+// chunks through a smaller block (hegvdx_core in evd.hip)
+constexpr int kZsCapMbDefault = 4096;
 // Panel width of the tridiagonalization: 32, the reference's own (zheevd_gpu.F90:63).  Rounds 1-3 used 64 (fewer, deeper rank-2nb
 // updates); with the round-4 mat-vec grid the narrower panel wins everywhere -- the per-column row kernel carries half the pending
 // columns: C3 trd 67.6 -> 66.6 ms, batch 17.66 -> 17.90 problems/s, C5 105.3 -> 109.9, C2 188.5 -> 194.0 (profiles/r04_experiments.txt 7).
@@ -182,11 +186,13 @@ struct Ctx {
                              // stream each); 0 = the lockstep form on the caller's own context (hegvdx_batch_core in evd.hip);
                              // -1 = automatic, see auto_batch_workers()
     int trace_marks = 0;     // EIGSOLVE_TRACE_MARKS=1: marker kernels at the phase boundaries (profiling aid, see evd.hip)
+    int zs_cap_mb = kZsCapMbDefault;
 
     template <class T> T* scratch(const char* name, size_t count) {
         return reinterpret_cast<T*>(scratch_bytes(name, count * sizeof(T)));
     }
     void* scratch_bytes(const char* name, size_t bytes);
+    void* try_scratch_bytes(const char* name, size_t bytes);   // nullptr instead of an exception when the device is out of memory
     void* host_scratch_bytes(const char* name, size_t bytes);
     void release();
     // Wait until everything THIS context has enqueued on `st` so far is done.  On a shared stream a

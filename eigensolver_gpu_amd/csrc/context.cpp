@@ -107,13 +107,28 @@ void* Ctx::scratch_bytes(const char* name, size_t bytes) {
         if (s.first) {
             if (lease_depth > 0) sync(s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
             if (s2) EIG_HIP(hipStreamSynchronize(s2));
-            EIG_HIP(hipFree(s.first));
+            void* old = s.first;
+            s.first = nullptr; s.second = 0;   // (a failing hipMalloc below must not leave a dangling pointer in the slot)
+            EIG_HIP(hipFree(old));
         }
         size_t cap = bytes + bytes / 8 + 256;
         EIG_HIP(hipMalloc(&s.first, cap));
         s.second = cap;
     }
     return s.first;
+}
+
+// like scratch_bytes, but "not enough device memory" is an answer (nullptr; the slot is then empty), not an exception
+void* Ctx::try_scratch_bytes(const char* name, size_t bytes) {
+    try {
+        return scratch_bytes(name, bytes);
+    } catch (const HipFail& f) {
+        if (f.err != hipErrorOutOfMemory && f.err != hipErrorMemoryAllocation) throw;
+        (void)hipGetLastError();
+        auto& s = slots[name];
+        s.first = nullptr; s.second = 0;
+        return nullptr;
+    }
 }
 
 void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
@@ -213,6 +228,7 @@ void copy_options(Ctx& c, const Ctx& d) {
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.real_il_reference = d.real_il_reference; c.tile_map = d.tile_map;
     c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.batch_fuse = d.batch_fuse; c.trd_finish = d.trd_finish;
+    c.zs_cap_mb = d.zs_cap_mb;
 }
 
 // ---- the library's worker threads ------------------------------------------------------------------------------------
@@ -356,7 +372,7 @@ void stream_pool_finalize(int dev) {
 // same value semantics, plus the words "host" / "device" for TRIDIAG and "rec" for POTRF) go through apply_option.
 static const char* const kOptionNames[] = {"trd_nb", "bt_nb", "hemv_blocks", "real_il_reference", "graph", "overlap", "trsm_base",
                                            "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "tridiag", "tile_map",
-                                           "trd_finish", "trace_marks"};
+                                           "trd_finish", "trace_marks", "zs_cap_mb"};
 bool apply_option(Ctx& c, const std::string& s, int value) {
     if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? kTrdNbDefault : value; c.drop_graphs(); }
     else if (s == "bt_nb") c.bt_nb = norm_bt_nb(value);
@@ -374,6 +390,7 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "tile_map") c.tile_map = value != 0;
     else if (s == "trd_finish") { c.trd_finish = value < 0 ? -1 : value; c.drop_graphs(); }
     else if (s == "trace_marks") c.trace_marks = value > 0;
+    else if (s == "zs_cap_mb") c.zs_cap_mb = value <= 0 ? kZsCapMbDefault : value;
     else return false;
     return true;
 }
@@ -387,9 +404,22 @@ static void init_options(Ctx& c) {
         for (const char* p = name; *p; ++p) env += (char)toupper((unsigned char)*p);
         const char* e = getenv(env.c_str());
         if (!e || !*e) continue;
-        int v = atoi(e);
-        if (e[0] == 'h' || e[0] == 'H' || e[0] == 'r' || e[0] == 'R') v = 0;          // TRIDIAG=host, POTRF=rec
-        else if (e[0] == 'd' || e[0] == 'D') v = 1;                                      // TRIDIAG=device
+        // Values are integers.  Words are accepted only where the header documents them: TRIDIAG=host|device, POTRF=rec.
+        // Anything else that is not a number is ignored with one line on stderr (it used to go through atoi and silently select
+        // setting 0, e.g. EIGSOLVE_OVERLAP=default switched the overlap off).
+        const std::string nm = name, val = e;
+        int v = 0;
+        char* end = nullptr;
+        const long lv = strtol(e, &end, 10);
+        while (end && (*end == ' ' || *end == '\t')) ++end;
+        if (end != e && end && *end == 0) v = (int)lv;
+        else if (nm == "tridiag" && (val == "host" || val == "HOST")) v = 0;
+        else if (nm == "tridiag" && (val == "device" || val == "DEVICE")) v = 1;
+        else if (nm == "potrf" && (val == "rec" || val == "REC")) v = 0;
+        else {
+            fprintf(stderr, "eigsolve: ignoring %s=%s (not an integer)\n", env.c_str(), e);
+            continue;
+        }
         (void)apply_option(c, name, v);
     }
 }

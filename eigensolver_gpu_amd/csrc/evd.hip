@@ -407,6 +407,17 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     return 0;
 }
 
+// hipHostMalloc'ed / hipHostRegister'ed memory?  (a device-to-host copy into anything else is staged and blocks the caller)
+static bool host_ptr_is_pinned(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 static void clear_phases(Ctx& c) {
     for (double& v : c.phase_ms) v = 0.0;
 }
@@ -453,26 +464,53 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     int info;
     // The eigenvectors of the standard problem are formed in library scratch (N x m) and the final solve writes Z = U^-1 Zs
     // out of place: no staging copies inside the solve (blas3.hip, trsm_LUN), and the caller's Z is written exactly once.
-    T* Zs = c.scratch<T>(Tr<T>::cx ? "evd_Zsz" : "evd_Zsd", (size_t)N * m);
+    // That copy costs sizeof(T) N m of device memory per context (C4: 1 GiB).  Beyond "zs_cap_mb" (default 4 GiB), or when the
+    // device cannot provide it, the vectors are formed in the CALLER's Z instead (as the reference does) and the solve runs in column
+    // chunks of mc vectors through a smaller block: Z(:, chunk) -> Zs, Zs -> Z(:, chunk).
+    const char* zs_slot = Tr<T>::cx ? "evd_Zsz" : "evd_Zsd";
+    int mc = m;
+    T* Zs = nullptr;
+    {
+        const size_t cap_elems = (size_t)c.zs_cap_mb * 1048576 / sizeof(T);
+        if ((size_t)N * m <= cap_elems) Zs = reinterpret_cast<T*>(c.try_scratch_bytes(zs_slot, sizeof(T) * (size_t)N * m));
+        if (!Zs) {
+            mc = (int)std::min<size_t>((size_t)m, std::max<size_t>(64, cap_elems / (size_t)N / 64 * 64));
+            if (mc >= m) mc = std::max(64, ((m / 2 + 63) / 64) * 64);
+            while (!(Zs = reinterpret_cast<T*>(c.try_scratch_bytes(zs_slot, sizeof(T) * (size_t)N * mc)))) {
+                if (mc <= 64) throw HipFail{hipErrorOutOfMemory};
+                mc = std::max(64, ((mc / 2 + 63) / 64) * 64);
+            }
+        }
+    }
+    const bool chunked = mc < m;
     {
         PhaseRange r(Tr<T>::cx ? "zheevd_gpu" : "dsyevd_gpu");   // :161
-        info = heevd_core<T>(c, il, iu, N, A, lda, Zs, N, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork, lswork, iwork,
-                             liwork);  // :163
+        info = heevd_core<T>(c, il, iu, N, A, lda, chunked ? Z : Zs, chunked ? ldz : N, w_d, e_d, tau_d, W_d, w_h, e_h, Q_h, ldq, swork,
+                             lswork, iwork, liwork);  // :163
     }
     if (info != 0) return -1;
     // The substitution finishes the row blocks of Z bottom-up, and the host copy of a finished block (a quarter of the rows) runs on
     // the second stream beside the rest of the solve (full-spectrum C4: Z is 1 GB, 19 ms over PCIe after a 39 ms solve -> 4.7 ms
     // exposed; C3: 1.19 -> 0.32 ms; below N*m = 2^20 the events cost what the copy gains).  Only for a solve that has the device
-    // to itself; the solve itself is unchanged, results are bit-identical.
+    // to itself and only into PINNED host memory: a copy into pageable memory is staged by the runtime and blocks the calling thread
+    // until the block's event has fired -- the rest of the solve would not even be queued meanwhile.  The solve itself is unchanged,
+    // results are bit-identical.
     // (Splitting the COLUMNS instead changes the split-K decisions of the products, and at m = 1024 half-width solves lose what the
     //  copy gains -- round 3.)
-    const bool zoverlap = !skip_host_copy && (long)N * m >= (long)EIG_ZOVERLAP_MIN && (c.overlap & 2) && !c.in_batch &&
-                          streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
+    const bool zoverlap = !skip_host_copy && !chunked && (long)N * m >= (long)EIG_ZOVERLAP_MIN && (c.overlap & 2) && !c.in_batch &&
+                          streams_in_use(c.dev) <= (c.s2 ? 2 : 1) && host_ptr_is_pinned(Z_h);
     bool copy_failed = false;
     {
         PhaseRange r(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167
         pt.begin(PH_TRSM);
-        if (!zoverlap) {
+        if (chunked) {
+            for (int j0 = 0; j0 < m; j0 += mc) {
+                const int wj = std::min(mc, m - j0);
+                T* Zj = Z + (size_t)j0 * ldz;
+                EIG_HIP(hipMemcpy2DAsync(Zs, sizeof(T) * N, Zj, sizeof(T) * ldz, sizeof(T) * N, wj, hipMemcpyDeviceToDevice, st));
+                trsm_LUN<T>(c, st, N, wj, B, ldb, 0, Zs, N, Zj, ldz, c.trsm_base);
+            }
+        } else if (!zoverlap) {
             trsm_LUN<T>(c, st, N, m, B, ldb, 0, Zs, N, Z, ldz, c.trsm_base);  // :169  Z = U^-1 Zs
         } else {
             hipStream_t sc = c.second_stream();

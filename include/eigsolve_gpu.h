@@ -40,8 +40,9 @@ int eigsolve_set_host_threads(int nthreads);
 
 /* Tunables (the reference hard-codes its own: trd nb=32 zheevd_gpu.F90:63, back-transform nb=64 :64, gst nb=448
  * zhegvdx_gpu.F90:156).  Every option is also read from the environment variable EIGSOLVE_<NAME> (upper case, same values;
- * TRIDIAG additionally accepts "host" / "device", POTRF "rec") when a context is created.  value <= 0 restores the default,
- * except where 0 is itself a setting (then value < 0 restores the default).
+ * TRIDIAG additionally accepts "host" / "device", POTRF "rec"; any other non-numeric value is ignored with a message on stderr) when a
+ * context is created.  value < 0 restores the default everywhere; value = 0 restores it too unless 0 is itself a setting of the
+ * option (tridiag, gst, potrf, overlap, batch_workers, hemv_blocks, trd_finish: 0 = the smallest cut-over, 32).
  *   "tridiag"   0 = host LAPACK dstedc exactly as the reference, 1 = device-side divide & conquer (default).
  *   "trd_nb"    panel width of the tridiagonalization, 1..64 (default 32 = the reference's, zheevd_gpu.F90:63; the caller's workspace contract bounds it).
  *   "trd_finish" order at which the blocked reduction hands the rest of the matrix to a one-workgroup kernel: -1 (default) =
@@ -55,8 +56,9 @@ int eigsolve_set_host_threads(int nthreads);
  *               nb = "trsm_base".
  *   "trsm_base" order of the inverted diagonal blocks the triangular solves outside potrf stop at: 64, 256 (default: the
  *               64-block inverses of the factorization merged), 512 or 1024.
- *   "potrf"     1 (default) right-looking Cholesky with block rows of 64 (one block-row kernel + one rank-64 MFMA update per
- *               block row), 0 the recursive form (no intra-grid dependency).
+ *   "potrf"     2 (default) right-looking Cholesky with block rows of 64 taken in pairs: a block-row kernel whose elimination is
+ *               blocked by 16 and runs on MFMA, one rank-128 MFMA update per pair; 1 the round-2 form (scalar block-row kernel, one
+ *               rank-64 update per block row); 0 the recursive form (no intra-grid dependency).
  *   "overlap"   bit mask of independent launch chains of one solve that run on a second stream (leased from the library's
  *               stream pool for the call): bit 0 = hegst beside the factorization, released stage by stage, bit 1 = larft T
  *               factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work) and, for N*m >= 2^20,
@@ -73,8 +75,15 @@ int eigsolve_set_host_threads(int nthreads);
  *   "graph"     1 = the tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working
  *               copy of A and replayed as a hipGraph; 0 (default) = eager launches (measured neutral).
  *   "tile_map"  1 (default) = XCD-aware super-tile order of the MFMA engine's workgroups, 0 = plain grids (A/B measurements).
- *   "hemv_blocks" workgroups of the panel mat-vec kernel (0 = automatic: two per CU).
+ *   "hemv_blocks" workgroups of the panel mat-vec kernel (0 = automatic: one per CU for a solve that has the device to itself,
+ *               3/4 of the CUs inside a batch call).
  *   "trace_marks" 1 = marker kernels at the phase boundaries (segments a rocprofv3 kernel trace, tools/trace_phases.py).
+ *   "zs_cap_mb" largest library-side copy (MiB, default 4096) of the standard problem's eigenvectors the generalized drivers keep:
+ *               they form those N x m vectors in library scratch (sizeof(T) N m bytes of device memory per context on top of the
+ *               caller's buffers: 64 MiB at C3, 1 GiB at C4 full spectrum; every worker context of a batch call has its own) and the
+ *               final triangular solve writes the caller's Z once.  Above the cap, or when the device cannot provide the block, the
+ *               vectors are formed in the caller's Z (as the reference does) and the solve runs in column chunks through a smaller
+ *               block -- same results to rounding.
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

@@ -13,9 +13,26 @@ SCRIPT = textwrap.dedent("""
     import os, sys, threading
     sys.path.insert(0, %r)
     import torch, torch.distributed as dist
-    from eigensolver_gpu_amd.batch import InflightPool, shard_problems, run_sharded_batch, gather_eigenvalues
+    from eigensolver_gpu_amd.batch import (InflightPool, shard_problems, run_sharded_batch, gather_eigenvalues,
+                                           gather_eigenvectors, rank_cpu_slice, pin_rank_to_cpu_slice)
+    # every rank keeps to its own share of the node's CPUs (bench.py does this before the library starts its workers)
+    before = sorted(os.sched_getaffinity(0))
+    lr, lw = int(os.environ["LOCAL_RANK"]), int(os.environ["LOCAL_WORLD_SIZE"])
+    mask = pin_rank_to_cpu_slice(lr, lw)
+    assert mask == sorted(os.sched_getaffinity(0)) and set(mask) <= set(before)
     dist.init_process_group(backend="gloo")
     r, w = dist.get_rank(), dist.get_world_size()
+    masks = [None] * w
+    dist.all_gather_object(masks, (before, mask))
+    if len(before) >= w:                      # enough CPUs: equal, disjoint, contiguous shares of the common mask
+        assert all(b == before for b, _ in masks)
+        assert all(len(mk) == len(before) // w for _, mk in masks)
+        allc = sum((mk for _, mk in masks), [])
+        assert len(allc) == len(set(allc)), "rank CPU masks overlap"
+        assert mask == rank_cpu_slice(before, lr, lw)
+    else:                                     # fewer CPUs than ranks: nobody is restricted
+        assert mask == before
+    assert rank_cpu_slice(range(256), 3, 8) == list(range(96, 128)) and rank_cpu_slice([5, 1, 3], 1, 8) == [1, 3, 5]
     NP, M = (64, 4) if w == 8 else (13, 4)          # world 8: BASELINE configs[4], 64 problems -> 8 per rank
     mine = shard_problems(NP, r, w)
     if w == 8:
@@ -57,6 +74,18 @@ SCRIPT = textwrap.dedent("""
             assert torch.equal(got[p], torch.linalg.eigvalsh(matrix(p))[:M]), p
     else:
         assert got is None
+    # optional gather of the eigenvector blocks (SURVEY.md 8(e)): problem p's block = m rows of length n, complex
+    NZ, MZ = 6, 3
+    def zblock(p):
+        g = torch.Generator().manual_seed(77 + p)
+        return torch.complex(torch.rand((MZ + 2, NZ), generator=g, dtype=torch.float64), torch.rand((MZ + 2, NZ), generator=g, dtype=torch.float64))
+    gz = gather_eigenvectors({p: zblock(p) for p in mine}, NP, NZ, MZ)
+    if r == 0:
+        assert gz.shape == (NP, MZ, NZ) and gz.dtype == torch.complex128
+        for p in range(NP):
+            assert torch.equal(gz[p], zblock(p)[:MZ]), p
+    else:
+        assert gz is None
     t = torch.tensor([1.0 + r], dtype=torch.float64)
     allt = [torch.empty_like(t) for _ in range(w)]
     dist.all_gather(allt, t)
@@ -94,7 +123,8 @@ def test_eight_rank_gloo(tmp_path):
 def test_bench_uses_the_batch_module():
     """bench.py's multi-GPU legs go through eigensolver_gpu_amd/batch.py (the functions the gloo test drives)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems", "host_threads_per_rank"):
+    for name in ("InflightPool", "run_sharded_batch", "gather_eigenvalues", "shard_problems", "host_threads_per_rank",
+                 "pin_rank_to_cpu_slice", "gather_eigenvectors"):
         assert name in src
 
 

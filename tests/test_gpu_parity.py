@@ -818,7 +818,8 @@ def test_optional_execution_modes_are_bit_identical(env, cplx, opt, n, m):
     """hipGraph replay and the two-chain pipeline (option "overlap": potrf's second half beside the part of hegst that only
     needs the first half of the factor, T factors beside the tridiagonal solver) only change HOW and WHEN the same kernels are
     issued: bit-identical to the one-stream eager path.  n > gst_thr for "overlap": below that the pipeline does not apply;
-    m >= 4096: the final solve runs in column chunks with the host copy of a finished chunk beside the next one."""
+    N*m >= 2^20 (and a pinned Z_h): the host copy of Z leaves in four ROW blocks on the second stream beside the final triangular
+    solve, whose launches are unchanged (a split by columns was measured and rejected: evd.hip)."""
     torch, oracle, api = env
     A = oracle.gen_spd_fast(n, 4000 + n, cplx)
     B = oracle.gen_spd_fast(n, 5000 + n, cplx, shift=float(n))
@@ -896,6 +897,93 @@ def test_leading_dimensions_larger_than_n(env, cplx, n, m):
     assert np.all(api.to_host(Ad)[:n, :][np.tril_indices(n, -1)] == -7.5)
     Uo, _ = oracle.potrf_upper(B)
     assert rel(np.triu(api.to_host(Bd)[:n, :]), np.triu(Uo)) <= 100 * n * EPS
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("pinned", [True, False])
+def test_eigenvector_scratch_cap_and_pageable_host_copy(env, cplx, pinned):
+    """Two memory-related modes of the generalized driver against its default form (N = 1100, m = 1000, padded leading dimensions):
+    * option zs_cap_mb = 1: the library's N x m copy of the standard problem's eigenvectors is capped, so they are formed in the
+      caller's Z and the final triangular solve runs in 64-column chunks through a small block (what happens beyond 4 GiB, or when
+      the device is short of memory) -- same answers to rounding, padding rows untouched;
+    * pageable Z_h: the host copy is NOT issued in row blocks beside the final solve (a copy into pageable memory blocks the calling
+      thread); the result is the one of the pinned form, bit for bit."""
+    torch, oracle, api = env
+    n, m = 1100, 1000
+    lda, ldb, ldz, ldzh = n + 3, n + 8, n + 5, n + 2
+    A = oracle.gen_spd_fast(n, 6100 + n, cplx)
+    B = oracle.gen_spd_fast(n, 7100 + n, cplx, shift=float(n))
+    dt = torch.complex128 if cplx else torch.float64
+
+    def padded(M, ld):
+        P = np.full((ld, n), 123.25, dtype=M.dtype, order="F")
+        P[:n, :] = np.triu(M)
+        return api.to_device(P)
+
+    def solve(cap):
+        Ad, Bd = padded(A, lda), padded(B, ldb)
+        ws = api.Workspace(n, cplx)
+        Zd = torch.full((n, ldz), 9.0, dtype=dt, device="cuda")
+        Zh = torch.full((n, ldzh), 5.0, dtype=dt)
+        if pinned:
+            Zh = Zh.pin_memory()
+        try:
+            api.set_option("zs_cap_mb", cap)
+            if cplx:
+                info = api.zhegvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.rwork, ws.lrwork, ws.work_h,
+                                       ws.lwork_h, ws.rwork_h, ws.lrwork_h, ws.iwork_h, ws.liwork_h, Zh, ldzh, ws.w_h)
+            else:
+                info = api.dsygvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.work_h, ws.lwork_h, ws.iwork_h,
+                                       ws.liwork_h, Zh, ldzh, ws.w_h)
+        finally:
+            api.set_option("zs_cap_mb", 0)
+        assert info == 0
+        Zhost = Zh.numpy().T
+        assert np.all(api.to_host(Zd)[n:, :] == 9.0) and np.all(Zhost[n:, :] == 5.0)
+        assert np.array_equal(api.to_host(Zd)[:n, :m], Zhost[:n, :m])
+        return ws.w_h.numpy().copy(), np.asfortranarray(Zhost[:n, :m])
+
+    w0, Z0 = solve(0)
+    w1, Z1 = solve(1)
+    assert oracle.residual(A, B, w0, Z0) <= n * EPS and oracle.residual(A, B, w1, Z1) <= n * EPS
+    assert np.array_equal(w0, w1)                       # the eigenvalues do not depend on where the vectors are formed
+    assert oracle.compare_abs2d(Z0, Z1)[0] <= 1e-10
+    if not pinned:                                       # same launches as the pinned form -> identical bits
+        Zp = torch.full((n, ldzh), 5.0, dtype=dt).pin_memory()
+        Ad, Bd = padded(A, lda), padded(B, ldb)
+        ws = api.Workspace(n, cplx)
+        Zd = torch.full((n, ldz), 9.0, dtype=dt, device="cuda")
+        if cplx:
+            api.zhegvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.rwork, ws.lrwork, ws.work_h,
+                            ws.lwork_h, ws.rwork_h, ws.lrwork_h, ws.iwork_h, ws.liwork_h, Zp, ldzh, ws.w_h)
+        else:
+            api.dsygvdx_gpu(n, Ad, lda, Bd, ldb, Zd, ldz, 1, m, ws.w, ws.work, ws.lwork, ws.work_h, ws.lwork_h, ws.iwork_h,
+                            ws.liwork_h, Zp, ldzh, ws.w_h)
+        assert np.array_equal(Zp.numpy().T[:n, :m], Z0)
+
+
+def test_environment_options_are_parsed_strictly(env):
+    """EIGSOLVE_<NAME>: integers, plus the documented words (TRIDIAG=host|device, POTRF=rec); anything else is ignored with a line on
+    stderr instead of silently selecting setting 0 (EIGSOLVE_OVERLAP=default used to switch the overlap off, EIGSOLVE_GST=hybrid the
+    hybrid reduction)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import torch; from eigensolver_gpu_amd import api; import oracle, numpy as np\n"
+            "torch.cuda.set_device(0); n, m = 300, 60\n"
+            "A = oracle.gen_spd_fast(n, 1, True); B = oracle.gen_spd_fast(n, 2, True, shift=float(n))\n"
+            "info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), 1, m)\n"
+            "assert info == 0; print('RES', oracle.residual(A, B, ws.w_h.numpy()[:n].copy(), np.asfortranarray(api.to_host(ws.Z_h, n, m))))\n"
+            "print('PH', api.phase_times()['stedc_host'])\n") % root
+    envv = dict(os.environ, EIGSOLVE_OVERLAP="default", EIGSOLVE_GST="hybrid", EIGSOLVE_TRIDIAG="host", EIGSOLVE_POTRF="rec",
+                EIGSOLVE_BT_NB=" 128 ", EIGSOLVE_TRD_NB="3x")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=envv)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    err = out.stderr
+    assert "ignoring EIGSOLVE_OVERLAP=default" in err and "ignoring EIGSOLVE_GST=hybrid" in err and "ignoring EIGSOLVE_TRD_NB=3x" in err
+    assert "EIGSOLVE_TRIDIAG" not in err and "EIGSOLVE_POTRF" not in err and "EIGSOLVE_BT_NB" not in err
+    res = float([l for l in out.stdout.splitlines() if l.startswith("RES")][-1].split()[1])
+    assert res <= 300 * EPS
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1407,6 +1495,34 @@ def test_bench_multi_rank_path_on_one_gpu(env):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["scaling"] == "strong" and d["config"]["problems_per_step_total"] == 64 and d["config"]["problems_per_gpu_per_step"] == 32
     assert d["eigenvalues_gathered"] == [64, 64] and d["residual"] < 1e-9
+
+
+def test_bench_rccl_world_of_one(env):
+    """The RCCL code path of bench.py on a 1-GPU box: `--force-dist --backend nccl` creates the process group (device_id binding)
+    with ONE rank and runs every collective of the multi-GPU legs -- dist.barrier, the timing all_gathers, gather_eigenvalues and the
+    optional eigenvector gather on device tensors -- over RCCL, once under torch.distributed.run (the driver's launcher) and once
+    launched plainly.  (Until round 5 nothing had ever executed `init_process_group(backend="nccl")`: every multi-rank test uses
+    gloo, and the first 8-GPU run would have been its first execution.)"""
+    import json
+    import subprocess
+    import sys
+    torch, oracle, api = env
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    envv["MASTER_ADDR"] = "127.0.0.1"
+    tail = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--order", "512", "--batch", "3", "--c5-order", "256", "--force-dist",
+            "--backend", "nccl", "--gather-z", "--no-roofline", "--no-cpu-baseline", "--no-host-tridiag"]
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+              "--master-port", "29541", os.path.join(root, "bench.py")]
+    for cmd in (launch + tail, [sys.executable, os.path.join(root, "bench.py")] + tail):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=envv)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["comm"] == dict(d["comm"], backend="nccl", ranks=1, forced=True)
+        assert d["eigenvalues_gathered"] == [3, 128]
+        assert d["eigenvectors_gathered"]["shape"] == [3, 128, 512] and d["eigenvectors_gathered"]["problems_present"] == 3
+        assert d["c5"]["gathered_eigenvalues_shape"] == [64, 64] and d["c5"]["rerun_bit_identical"] is True
+        assert d["residual"] < 1e-9 and d["strict_gate"]["pass"] is True
 
 
 def test_bench_default_line_every_object(env):
