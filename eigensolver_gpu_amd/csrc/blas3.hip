@@ -1862,8 +1862,10 @@ template <class T> static void hegst_pregrow(Ctx& c, int N) {
         const int nb = gran < 256 ? 256 : gran;
         qT = (size_t)nb * N; qH = (size_t)nb * nb; qF = (size_t)nb * nb;
     } else if (c.gst_mode == 0 || N < 256) {
-        const int n1 = split_n1(N);
-        qT = (size_t)n1 * (N - n1) + 64; qH = (size_t)n1 * n1;
+        if (N > DB) {                              // (orders up to 64 are one block: no block step)
+            const int n1 = split_n1(N);
+            qT = (size_t)n1 * (N - n1) + 64; qH = (size_t)n1 * n1;
+        }
     } else {
         qF = (size_t)N * N;
     }
