@@ -121,6 +121,9 @@ template <class T> bool pipeline_applicable(const Ctx& c, int N);
 template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda, T* B, int ldb);
 template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, const T* U, int ldu);
 
+// launch skeleton of stage 1 of a two-stage reduction (timing only; see blas3.hip)
+template <class T> void two_stage_stage1_skeleton(Ctx& c, hipStream_t st, int N, int what);
+
 inline constexpr int kDiagBlk = 64;  // order of the inverted diagonal blocks
 
 }  // namespace eig

@@ -330,6 +330,9 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         EIG_HIP(hipMemcpyAsync(tau_d, tauw, sizeof(T) * (N - 1), hipMemcpyDeviceToDevice, st));
         Vsrc = Aw; ldv = N; tau_bt = tauw;
     } else {
+        // (A padded working copy for the one column stride that streams slower from HBM -- exactly 128 KB, complex lda = 8192 =
+        //  BASELINE's C4: the mat-vec launches alone gain 5 % there, profiles/r04_experiments.txt 18 -- was built in round 5 and
+        //  LOSES in the whole tridiagonalization: 384 -> 396 ms at C4, twice, profiles/r05_experiments.txt 3.  Removed.)
         hetrd_upper<T>(c, st, N, A, lda, w_d, e_d, tau_d, W_d, c.trd_nb);
     }
     pt.end(PH_TRD);
@@ -1061,6 +1064,15 @@ extern "C" int eigsolve_dgemm_probe(char ta, char tb, int M, int N, int K, const
                                     double* C_d, int ldc, int reps, int beta_one, int maskA, int moffA, int maskB, int moffB,
                                     double* ms_avg) {
     return gemm_probe_entry<double>(ta, tb, M, N, K, A_d, lda, B_d, ldb, C_d, ldc, reps, beta_one, maskA, moffA, maskB, moffB, ms_avg);
+}
+
+// timing hook (tools/two_stage_model.py): the launch skeleton of stage 1 of a two-stage reduction, ms per pass
+extern "C" int eigsolve_debug_two_stage_model(int N, int cplx_, int what, int reps, double* ms_avg) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        if (cplx_) return bench_loop<cplx>(c, reps, ms_avg, [&]() { two_stage_stage1_skeleton<cplx>(c, c.s1, N, what); });
+        return bench_loop<double>(c, reps, ms_avg, [&]() { two_stage_stage1_skeleton<double>(c, c.s1, N, what); });
+    });
 }
 
 template <class T> static int her2k_entry(int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc, int reps, double* ms) {

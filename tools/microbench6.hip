@@ -59,38 +59,46 @@ __global__ void __launch_bounds__(320) rhythm_kernel(const d2* A, long lda, int 
     d2 acc = {0.0, 0.0};
     d2 v[16];
     int t = blockIdx.x;
-    auto addr = [&](int tt, int j) -> const d2* {
-        const int2 q = tiles[tt < ntiles ? tt : ntiles - 1];
-        long r = (long)q.x * 64 + lane, c = (long)q.y * 64 + (wave & 3) * 16 + j;
-        r = r < n ? r : n - 1; c = c < n ? c : n - 1;
+    // tile tt = J(J+1)/2 + I of the upper triangle, decoded arithmetically once per tile; returns the lane's base pointer
+    auto base_of = [&](int tt) -> const d2* {
+        tt = tt < ntiles ? tt : ntiles - 1;
+        int J = (int)((__builtin_sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f);
+        while ((J + 1) * (J + 2) / 2 <= tt) ++J;
+        while (J * (J + 1) / 2 > tt) --J;
+        const int I = tt - J * (J + 1) / 2;
+        long r = (long)I * 64 + lane, c = (long)J * 64 + (wave & 3) * 16;
+        r = r < n ? r : n - 1; c = c + 15 < n ? c : n - 16;
         return A + r + c * lda;
     };
+    const d2* bp = base_of(t);
     if (wave < 4 && t < ntiles) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = *addr(t, j);
+        for (int j = 0; j < 16; ++j) v[j] = bp[j * lda];
     }
     for (; t < ntiles; t += gridDim.x) {
         if (wave < 4) {
+            const bool more = t + (int)gridDim.x < ntiles;
+            const d2* np = base_of(t + gridDim.x);
             d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < 8; ++j) s0 += v[j];
-            if (MODE == 2 && t + gridDim.x < ntiles) {
+            if (MODE == 2 && more) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = *addr(t + gridDim.x, j);
+                for (int j = 0; j < 8; ++j) v[j] = np[j * lda];
             }
 #pragma unroll
             for (int j = 8; j < 16; ++j) s1 += v[j];
-            if (MODE == 2 && t + gridDim.x < ntiles) {
+            if (MODE == 2 && more) {
 #pragma unroll
-                for (int j = 8; j < 16; ++j) v[j] = *addr(t + gridDim.x, j);
+                for (int j = 8; j < 16; ++j) v[j] = np[j * lda];
             }
             double x = s0.x + s1.y, y = s0.y + s1.x;
             for (int k = 0; k < work; ++k) { x = fma(x, 1.0000001, y); y = fma(y, 0.9999999, x); }     // dependent chain: ~22 cycles per iteration
             acc.x += x; acc.y += y;
             sh[wave][lane] = x;
-            if (MODE == 1 && t + gridDim.x < ntiles) {
+            if (MODE == 1 && more) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) v[j] = *addr(t + gridDim.x, j);
+                for (int j = 0; j < 16; ++j) v[j] = np[j * lda];
             }
         }
         __syncthreads();
