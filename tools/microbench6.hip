@@ -50,8 +50,8 @@ __global__ void __launch_bounds__(256) stream_kernel(const d2* A, long lda, int 
 // The same stream with panel_mv_kernel's per-tile rhythm (64 x 64 tiles): every wave spends `work` dependent multiply-adds per tile
 // on the data (the products + the transpose-reduce of the real kernel: ~1500 cycles) and the workgroup meets at a barrier per tile.
 //   MODE 1: the next tile's loads are issued AFTER the work on the current one (the round-4 kernel): nothing in flight meanwhile.
-//   MODE 2: rolling issue -- the loads of the next tile go out right after the current tile's registers have been read, half a
-//           tile at a time, so 16 loads per lane stay in flight through the work.
+//   MODE 2: two tiles in flight (double-buffered registers, loop unrolled by two): the loads of tile k+2 go out right after tile k
+//           has been worked on, tile k+1 is in flight throughout.
 template <int MODE>
 __global__ void __launch_bounds__(320) rhythm_kernel(const d2* A, long lda, int n, const int2* tiles, int ntiles, d2* out, int work) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,39 +70,70 @@ __global__ void __launch_bounds__(320) rhythm_kernel(const d2* A, long lda, int 
         r = r < n ? r : n - 1; c = c + 15 < n ? c : n - 16;
         return A + r + c * lda;
     };
-    const d2* bp = base_of(t);
-    if (wave < 4 && t < ntiles) {
+    const int G = gridDim.x;
+    auto work_on = [&](const d2 (&w)[16]) {
+        d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = bp[j * lda];
-    }
-    for (; t < ntiles; t += gridDim.x) {
+        for (int j = 0; j < 8; ++j) s0 += w[j];
+#pragma unroll
+        for (int j = 8; j < 16; ++j) s1 += w[j];
+        double x = s0.x + s1.y, y = s0.y + s1.x;
+        for (int k = 0; k < work; ++k) { x = fma(x, 1.0000001, y); y = fma(y, 0.9999999, x); }     // dependent chain: ~22 cycles per iteration
+        acc.x += x; acc.y += y;
+        sh[wave][lane] = x;
+    };
+    auto finish = [&]() {
+        __syncthreads();
+        if (wave == 4) acc.x += sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+    };
+    if (MODE == 1) {
+        const d2* bp = base_of(t);
+        if (wave < 4 && t < ntiles) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = bp[j * lda];
+        }
+        for (; t < ntiles; t += G) {
+            if (wave < 4) {
+                const bool more = t + G < ntiles;
+                const d2* np = base_of(t + G);
+                work_on(v);
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v[j] = np[j * lda];
+                }
+            }
+            finish();
+        }
+    } else {
+        // two tiles in flight: buffer u holds tile t + G while tile t (buffer v) is worked on; the loop is unrolled by two so that
+        // no register copies (and the waits they imply) separate the iterations
+        d2 u[16];
         if (wave < 4) {
-            const bool more = t + (int)gridDim.x < ntiles;
-            const d2* np = base_of(t + gridDim.x);
-            d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+            const d2* b0 = base_of(t);
+            const d2* b1 = base_of(t + G);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s0 += v[j];
-            if (MODE == 2 && more) {
+            for (int j = 0; j < 16; ++j) v[j] = b0[j * lda];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = np[j * lda];
-            }
-#pragma unroll
-            for (int j = 8; j < 16; ++j) s1 += v[j];
-            if (MODE == 2 && more) {
-#pragma unroll
-                for (int j = 8; j < 16; ++j) v[j] = np[j * lda];
-            }
-            double x = s0.x + s1.y, y = s0.y + s1.x;
-            for (int k = 0; k < work; ++k) { x = fma(x, 1.0000001, y); y = fma(y, 0.9999999, x); }     // dependent chain: ~22 cycles per iteration
-            acc.x += x; acc.y += y;
-            sh[wave][lane] = x;
-            if (MODE == 1 && more) {
+            for (int j = 0; j < 16; ++j) u[j] = b1[j * lda];
+        }
+        for (; t < ntiles; t += 2 * G) {
+            if (wave < 4) {
+                work_on(v);
+                const d2* np = base_of(t + 2 * G);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = np[j * lda];
             }
+            finish();
+            if (t + G < ntiles) {
+                if (wave < 4) {
+                    work_on(u);
+                    const d2* np = base_of(t + 3 * G);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) u[j] = np[j * lda];
+                }
+                finish();
+            }
         }
-        __syncthreads();
-        if (wave == 4) acc.x += sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
     }
     if (acc.x == 12345.678) out[blockIdx.x * 320 + threadIdx.x] = acc;
 }
@@ -169,7 +200,7 @@ int main(int argc, char** argv) {
     printf("  256x16 %.0f", run<256, 16>(A, lda, n, out, reps, grid));
     printf("  512x8 %.0f GB/s\n", run<512, 8>(A, lda, n, out, reps, grid));
     for (int work : {0, 30, 60, 90})
-        printf("   rhythm (64x64, barrier per tile, %4d dependent fma pairs of work per tile):  issue-after-work %.0f   rolling issue %.0f GB/s\n",
+        printf("   rhythm (64x64, barrier per tile, %4d dependent fma pairs of work per tile):  issue-after-work %.0f   two tiles in flight %.0f GB/s\n",
                work, run_rhythm<1>(A, lda, n, out, reps, grid, work), run_rhythm<2>(A, lda, n, out, reps, grid, work));
     return 0;
 }

@@ -31,7 +31,7 @@ for case in range(cases):
     m = iu - il + 1
     opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 4)),
             "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256, 256, 512, 1024])),
-            "trd_nb": int(rng.choice([64, 32, 17])), "potrf": int(rng.choice([1, 1, 0])), "trd_finish": int(rng.choice([-1, -1, 32, 64, 100])),
+            "trd_nb": int(rng.choice([64, 32, 17])), "potrf": int(rng.choice([2, 2, 1, 0])), "zs_cap_mb": int(rng.choice([0, 0, 0, 1])), "trd_finish": int(rng.choice([-1, -1, 32, 64, 100])),
             "tile_map": int(rng.integers(0, 2))}
     for k, v in opts.items(): assert api.set_option(k, v) == 0
     A = gen_spd(n, 100 + case, cplx)
@@ -48,6 +48,6 @@ for case in range(cases):
     print("%s case %3d n=%4d %s il=%4d iu=%4d %s res=%.2e orth=%.2e" % ("ok " if ok else "BAD", case, n, "z" if cplx else "d", il, iu, opts, res, orth), flush=True)
 for k in ("tridiag", "gst"): api.set_option(k, -1)
 for k in ("bt_nb", "gst_thr", "trsm_base", "trd_nb"): api.set_option(k, 0)
-api.set_option("potrf", 1); api.set_option("trd_finish", -1); api.set_option("tile_map", 1)
+api.set_option("potrf", -1); api.set_option("trd_finish", -1); api.set_option("tile_map", 1); api.set_option("zs_cap_mb", 0)
 print("%d cases, %d bad, %.1f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
