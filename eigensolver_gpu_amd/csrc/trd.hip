@@ -297,7 +297,8 @@ extern "C" int eigsolve_debug_trd_timing(unsigned long long* out36) {
 // and hide under the bandwidth-bound tiles.  Loads are issued before the scalar prologue.
 // ------------------------------------------------------------------------------------------
 #ifndef EIG_MV_SKIP
-#define EIG_MV_SKIP 0     // (timing variants of panel_mv_kernel: bit 0 no cross-lane column reduction, bit 1 no products -- wrong results, same loads)
+#define EIG_MV_SKIP 0     // (timing variants of panel_mv_kernel: bit 0 no cross-lane column reduction, bit 1 no products, bit 2 no partial-sum
+                          //  stores -- wrong results, same tile loads)
 #endif
 __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
     // t = J(J+1)/2 + I, I <= J.  Single-precision estimate (one v_sqrt_f32) + exact integer correction.
@@ -518,7 +519,10 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         T tv = scale * redt[rb][lane];
         T vI = scale * xr + unit(r0 + lane);
         T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
-        if (diag) {
+        if (EIG_MV_SKIP & 4) {
+            fmac_(Sacc, vI, yv);
+            fmac_(Sacc, vJ, tv);
+        } else if (diag) {
             T s = yv + tv;
             a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
             fmac_(Sacc, vI, s);
