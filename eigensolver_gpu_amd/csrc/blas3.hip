@@ -20,6 +20,16 @@
 #include "blas3.h"
 #include "lanes.h"
 
+// Real tiles use ONE v_mfma_f64_16x16x4 per 16x16x4 block product, complex tiles four v_mfma_f64_4x4x4 (round 5).  A bare stream of
+// the 4x4x4 form sustains 72 TFLOP/s against 48 for 16x16x4 (profiles/r01_microbench3_mfma_variants.txt), and the complex tiles --
+// 256 MFMAs per wave and K-slab, MFMA pipe 74 % busy -- live off that.  A real tile has a quarter of the MFMA work per staged
+// element and is bound by everything around it: the 16x16x4 form needs one B-fragment read instead of four and a quarter of the
+// issue slots: dgemm 4096^3 41.3 -> 45.5 TFLOP/s, 2048^3 37.9 -> 41.6, 8192^2 x 256 38.4 -> 42.2 (EIG_REAL_MFMA16=0 restores the
+// 4x4x4 form for A/B runs; same lane -> (m, n) mapping of the result, same summation order over k: bit-identical).
+#ifndef EIG_REAL_MFMA16
+#define EIG_REAL_MFMA16 1
+#endif
+
 namespace eig {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -343,7 +353,25 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     // (replicated over lane bits 2-3) against the unchanged 16-wide A fragment, produce exactly one 16x16x4 product; result r
     // lands in component r of the accumulator: lane l holds C(m = l&15, n = 4r + (l>>4))
     // (layout measured in profiles/r01_probe_mfma_f64_4x4x4_layout.txt).  blgp bit 0 negates.
+    constexpr bool M16 = !CX && EIG_REAL_MFMA16;
     auto mma_slab = [&](const double* As, const double* Bs) {
+        if constexpr (M16) {
+            // D'[n][m] = sum_k Bt(n, k) A(m, k): first operand lane l = Bt(n = l & 15, k = l >> 4), second = A(m = l & 15, k = l >> 4);
+            // result lane l, component r = C(m = l & 15, n = 4 r + (l >> 4)) -- the layout the four 4x4x4 products reproduce
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                double ar[TM], br[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) ar[a] = As[aoff(wm0 + a * 16 + fi, kk + fk)];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) br[b] = Bs[boff(wn0 + b * 16 + fi, kk + fk)];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ar[a], acc[0][a][b], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             double ar[TM], ai[TM], br[TN][4], bi[TN][4];
