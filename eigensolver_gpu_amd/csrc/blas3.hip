@@ -354,7 +354,38 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     // lands in component r of the accumulator: lane l holds C(m = l&15, n = 4r + (l>>4))
     // (layout measured in profiles/r01_probe_mfma_f64_4x4x4_layout.txt).  blgp bit 0 negates.
     constexpr bool M16 = !CX && EIG_REAL_MFMA16;
+    // the complex 32x32 tiles (the <= 256-workgroup launches of hegst / trsm / the T factors: latency-bound, MFMA pipe 20-30 % busy) take
+    // the 16x16x4 form too: gst 7.69 -> 7.54 ms at C3, C5 batch 108.8 -> 109.9 problems/s; the 64x64 complex tiles keep 4x4x4
+#ifndef EIG_CPLX_SMALL_MFMA16
+#define EIG_CPLX_SMALL_MFMA16 1
+#endif
+    constexpr bool C16 = CX && EIG_CPLX_SMALL_MFMA16 && BM * BN <= 32 * 32;
     auto mma_slab = [&](const double* As, const double* Bs) {
+        if constexpr (C16) {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                double ar[TM], ai[TM], br[TN], bi[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) { const int off = aoff(wm0 + a * 16 + fi, kk + fk); ar[a] = As[off]; ai[a] = As[ASZ + off]; }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) { const int off = boff(wn0 + b * 16 + fi, kk + fk); br[b] = Bs[off]; bi[b] = Bs[BSZ + off]; }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ar[a], acc[0][a][b], 0, 0, 0);
+                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ar[a], acc[NPL - 1][a][b], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ai[a], acc[0][a][b], 0, 0, 1);
+                        acc[NPL - 1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ai[a], acc[NPL - 1][a][b], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         if constexpr (M16) {
             // D'[n][m] = sum_k Bt(n, k) A(m, k): first operand lane l = Bt(n = l & 15, k = l >> 4), second = A(m = l & 15, k = l >> 4);
             // result lane l, component r = C(m = l & 15, n = 4 r + (l >> 4)) -- the layout the four 4x4x4 products reproduce
