@@ -359,7 +359,13 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
 #ifndef EIG_CPLX_SMALL_MFMA16
 #define EIG_CPLX_SMALL_MFMA16 1
 #endif
-    constexpr bool C16 = CX && EIG_CPLX_SMALL_MFMA16 && BM * BN <= 32 * 32;
+    // ... and so do the complex 64x64 tiles: on every shape of tools/gemm_shapes.py, fat ones included (zgemm 4096^3 58.3 -> 61.2
+    // TFLOP/s, rank-64 update of order 4032 45.0 -> 47.8; in the C3 solve on one stream gst 7.49 -> 7.14, back-transformation
+    // 4.56 -> 4.33, potrf 4.82 -> 4.70 ms).  The 48 TFLOP/s "ceiling" of round 1's bare 16x16x4 stream does not describe this kernel.
+#ifndef EIG_CPLX_BIG_MFMA16
+#define EIG_CPLX_BIG_MFMA16 1
+#endif
+    constexpr bool C16 = CX && ((EIG_CPLX_SMALL_MFMA16 && BM * BN <= 32 * 32) || (EIG_CPLX_BIG_MFMA16 && BM * BN > 32 * 32));
     auto mma_slab = [&](const double* As, const double* Bs) {
         if constexpr (C16) {
 #pragma unroll
