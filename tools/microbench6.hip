@@ -23,6 +23,7 @@ __global__ void __launch_bounds__(256) stream_kernel(const d2* A, long lda, int 
     d2 acc = {0.0, 0.0};
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int2 tt = tiles[t];
+        if (tt.x < 0) continue;       // (hole of a run-ordered list, see reorder())
         const long r0 = (long)tt.x * TR, c0 = (long)tt.y * TC;
         d2 v[16];
         // wave layout inside the tile
@@ -160,12 +161,55 @@ template <int MODE> static double run_rhythm(const d2* A, long lda, int n, d2* o
     return (double)tl.size() * 64 * 64 * 16.0 * reps / (ms * 1e-3) * 1e-9;
 }
 
+// Tile ORDER experiment (round 5, section 10 of r05_experiments.txt): the kernels deal list entry t to workgroup t mod G.
+//   order 0: the list as built (column-major over the triangle): at any moment the G workgroups read G consecutive tiles -- a compact
+//            window of one or two tile columns;
+//   order 1: workgroup hb reads a RUN of L consecutive tiles of the column-major order (entry k G + hb = tile hb L + k): every
+//            workgroup streams down its own tile column, the G workgroups are spread over the whole matrix;
+//   order 2: the same with the tiles first put in strips of 4 tile columns, row by row (the order of trd.hip's SlotMap).
+static int g_order = 0;
+static std::vector<int2> reorder(const std::vector<int2>& cm, int G) {
+    if (g_order == 0) return cm;
+    std::vector<int2> src = cm;
+    if (g_order == 2) {
+        int nt = 0;
+        for (auto& t : cm) nt = t.y + 1 > nt ? t.y + 1 : nt;
+        src.clear();
+        const int w = 4, ws0 = nt - w * ((nt - 1) / w);
+        for (int J0 = 0, wd = ws0; J0 < nt; J0 += wd, wd = w)
+            for (int I = 0; I < J0 + wd; ++I)
+                for (int J = (I > J0 ? I : J0); J < J0 + wd; ++J) src.push_back(make_int2(I, J));
+    }
+    const int M = (int)src.size(), L = (M + G - 1) / G;
+    std::vector<int2> out((size_t)L * G, make_int2(-1, -1));
+    for (int hb = 0; hb < G; ++hb)
+        for (int k = 0; k < L && hb * L + k < M; ++k) out[(size_t)k * G + hb] = src[hb * L + k];
+    return out;
+}
+
 template <int TR, int TC> static double run(const d2* A, long lda, int n, d2* out, int reps, int grid) {
     std::vector<int2> tl;
     const int ntr = (n + TR - 1) / TR, ntc = (n + TC - 1) / TC;
     for (int j = 0; j < ntc; ++j)
         for (int i = 0; i < ntr; ++i)
             if ((long)i * TR <= (long)(j + 1) * TC - 1) tl.push_back(make_int2(i, j));
+    const size_t nreal = tl.size();
+    if (TR == 64 && TC == 64) tl = reorder(tl, grid);
+    if (TR == 256 && TC == 16 && g_order == 3) {
+        // balanced ROW runs: the tiles in row-major order (row block i, then j), workgroup hb takes [hb M / G, (hb + 1) M / G)
+        std::vector<int2> rm;
+        for (int i = 0; i < ntr; ++i)
+            for (int j = 0; j < ntc; ++j)
+                if ((long)i * TR <= (long)(j + 1) * TC - 1) rm.push_back(make_int2(i, j));
+        const long M = (long)rm.size();
+        const int L = (int)((M + grid - 1) / grid);
+        std::vector<int2> out((size_t)L * grid, make_int2(-1, -1));
+        for (int hb = 0; hb < grid; ++hb) {
+            const long a = hb * M / grid, b = (hb + 1) * M / grid;
+            for (long k = a; k < b; ++k) out[(size_t)(k - a) * grid + hb] = rm[k];
+        }
+        tl = out;
+    }
     int2* d_t;
     CK(hipMalloc(&d_t, tl.size() * sizeof(int2)));
     CK(hipMemcpy(d_t, tl.data(), tl.size() * sizeof(int2), hipMemcpyHostToDevice));
@@ -180,7 +224,7 @@ template <int TR, int TC> static double run(const d2* A, long lda, int n, d2* ou
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipFree(d_t));
-    const double bytes = (double)tl.size() * TR * TC * 16.0;
+    const double bytes = (double)nreal * TR * TC * 16.0;
     return bytes * reps / (ms * 1e-3) * 1e-9;
 }
 
@@ -190,6 +234,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 3 ? atoi(argv[3]) : 10;
     const int grid = argc > 4 ? atoi(argv[4]) : 256;
     const long lda = n + pad;
+    const int orders = argc > 5 ? atoi(argv[5]) : 0;     // 1: also time the 64 x 64 stream in the run orders
     d2 *A, *out;
     CK(hipMalloc(&A, (size_t)lda * n * sizeof(d2)));
     CK(hipMemset(A, 0, (size_t)lda * n * sizeof(d2)));
@@ -199,6 +244,19 @@ int main(int argc, char** argv) {
     printf("  128x32 %.0f", run<128, 32>(A, lda, n, out, reps, grid));
     printf("  256x16 %.0f", run<256, 16>(A, lda, n, out, reps, grid));
     printf("  512x8 %.0f GB/s\n", run<512, 8>(A, lda, n, out, reps, grid));
+    if (orders) {
+        printf("   64x64 stream by tile order: ");
+        for (int rep = 0; rep < 2; ++rep)
+            for (g_order = 0; g_order < 3; ++g_order)
+                printf(" %s %.0f", g_order == 0 ? "column-major round-robin" : (g_order == 1 ? "column runs" : "strip-4 runs"), run<64, 64>(A, lda, n, out, reps, grid));
+        printf(" GB/s\n   256x16 stream by tile order: ");
+        for (int rep = 0; rep < 2; ++rep) {
+            g_order = 0; printf(" column-major round-robin %.0f", run<256, 16>(A, lda, n, out, reps, grid));
+            g_order = 3; printf(" balanced row runs %.0f", run<256, 16>(A, lda, n, out, reps, grid));
+        }
+        g_order = 0;
+        printf(" GB/s\n");
+    }
     for (int work : {0, 30, 60, 90})
         printf("   rhythm (64x64, barrier per tile, %4d dependent fma pairs of work per tile):  issue-after-work %.0f   two tiles in flight %.0f GB/s\n",
                work, run_rhythm<1>(A, lda, n, out, reps, grid, work), run_rhythm<2>(A, lda, n, out, reps, grid, work));
