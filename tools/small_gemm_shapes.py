@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Times the MFMA engine on the <= 256-workgroup (32 x 32 tile) products of hegst / trsm / the T factors, with the deep-slab
-option on and off in one process.  Usage: python tools/small_gemm_shapes.py [real]"""
+"""Times the MFMA engine on the <= 256-workgroup (32 x 32 tile) products of hegst / trsm / the T factors (two passes).  A/B a
+compile-time variant with EIGSOLVE_GPU_LIB=<variant .so> (make OUTDIR=../lib/v_x EXTRA=-D...), both commands in one gpurun call.
+Usage: python tools/small_gemm_shapes.py [real]"""
 import os
 import sys
 
@@ -23,8 +24,7 @@ shapes = [("N", "N", 256, 1024, 256), ("C", "N", 256, 1024, 256), ("N", "C", 256
           ("N", "N", 512, 512, 512), ("N", "N", 256, 1024, 128), ("N", "N", 256, 2048, 256), ("N", "N", 64, 2048, 2048)]
 for ta, tb, M, N, K in shapes:
     out = []
-    for deep in (0, 1, 0, 1):
-        api.set_option("deep_slab", deep)
+    for rep in range(2):
         ms = api.gemm_bench(ta, tb, M, N, K, A, big, B, big, C, big, reps=20)
-        out.append("%7.1f us %5.1f TF" % (ms * 1e3, cm * M * N * K / (ms * 1e-3) * 1e-12))
-    print("%s%s M=%5d N=%5d K=%5d   shallow %s | deep %s | shallow %s | deep %s" % (ta, tb, M, N, K, out[0], out[1], out[2], out[3]), flush=True)
+        out.append("%7.1f us %5.1f TFLOP/s" % (ms * 1e3, cm * M * N * K / (ms * 1e-3) * 1e-12))
+    print("%s%s M=%5d N=%5d K=%5d   %s | %s" % (ta, tb, M, N, K, out[0], out[1]), flush=True)
