@@ -32,22 +32,34 @@ for case in range(cases):
     opts = {"tridiag": int(rng.integers(0, 2)), "bt_nb": int(rng.choice([64, 128])), "gst": int(rng.integers(0, 4)),
             "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256, 256, 512, 1024])),
             "trd_nb": int(rng.choice([64, 32, 17])), "potrf": int(rng.choice([2, 2, 1, 0])), "zs_cap_mb": int(rng.choice([0, 0, 0, 1])), "trd_finish": int(rng.choice([-1, -1, 32, 64, 100])),
-            "tile_map": int(rng.integers(0, 2))}
+            "tile_map": int(rng.integers(0, 2)), "hemv_blocks": int(rng.choice([0, 0, 0, 3, 40, 512])),
+            "batch_workers": int(rng.choice([-1, -1, 0, 2])), "batch_fuse": int(rng.choice([-1, -1, 1, 3]))}
+    # one case in five goes through the batch entry point: 2-5 distinct problems of this order in one call, each checked
+    # (the batch interface carries no host workspaces: it needs the device tridiagonal solver and says so otherwise)
+    nprob = int(rng.integers(2, 6)) if (rng.random() < 0.2 and n <= 700) else 1
+    if nprob > 1: opts["tridiag"] = 1
     for k, v in opts.items(): assert api.set_option(k, v) == 0
-    A = gen_spd(n, 100 + case, cplx)
-    B = gen_spd(n, 200 + case, cplx, shift=float(n))
-    info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), il, iu)
-    w = ws.w_h.numpy()[:n].copy(); Z = np.asfortranarray(api.to_host(ws.Z_h, n, m)).copy()
-    R = A @ Z - (B @ Z) * w[il - 1:iu]
-    res = np.linalg.norm(R) / np.linalg.norm(A)
-    orth = np.abs(Z.conj().T @ (B @ Z) - np.eye(m)).max()
-    srt = bool(np.all(np.diff(w) >= 0))
-    ok = info == 0 and res <= max(n, 4) * EPS and orth <= 1e-11 and srt and np.all(np.isfinite(Z))
+    probs = [(gen_spd(n, 100 + case + 1000 * q, cplx), gen_spd(n, 200 + case + 1000 * q, cplx, shift=float(n))) for q in range(nprob)]
+    if nprob == 1:
+        info, ws = api.hegvdx(api.to_device(np.triu(probs[0][0])), api.to_device(np.triu(probs[0][1])), il, iu)
+        infos, wss = [info], [ws]
+    else:
+        wss = [api.Workspace(n, cplx) for _ in range(nprob)]
+        infos = api.hegvdx_batch([(api.to_device(np.triu(a)), api.to_device(np.triu(b))) for a, b in probs], il, iu, wss)
+    ok, res, orth = True, 0.0, 0.0
+    for (A, B), info, ws in zip(probs, infos, wss):
+        w = ws.w_h.numpy()[:n].copy(); Z = np.asfortranarray(api.to_host(ws.Z_h, n, m)).copy()
+        R = A @ Z - (B @ Z) * w[il - 1:iu]
+        res = max(res, np.linalg.norm(R) / np.linalg.norm(A))
+        orth = max(orth, np.abs(Z.conj().T @ (B @ Z) - np.eye(m)).max())
+        srt = bool(np.all(np.diff(w) >= 0))
+        ok = ok and info == 0 and res <= max(n, 4) * EPS and orth <= 1e-11 and srt and bool(np.all(np.isfinite(Z)))
     if not ok:
         bad += 1
-    print("%s case %3d n=%4d %s il=%4d iu=%4d %s res=%.2e orth=%.2e" % ("ok " if ok else "BAD", case, n, "z" if cplx else "d", il, iu, opts, res, orth), flush=True)
+    print("%s case %3d n=%4d %s il=%4d iu=%4d batch=%d %s res=%.2e orth=%.2e" % ("ok " if ok else "BAD", case, n, "z" if cplx else "d", il, iu, nprob, opts, res, orth), flush=True)
 for k in ("tridiag", "gst"): api.set_option(k, -1)
 for k in ("bt_nb", "gst_thr", "trsm_base", "trd_nb"): api.set_option(k, 0)
 api.set_option("potrf", -1); api.set_option("trd_finish", -1); api.set_option("tile_map", 1); api.set_option("zs_cap_mb", 0)
+api.set_option("hemv_blocks", 0); api.set_option("batch_workers", -1); api.set_option("batch_fuse", -1)
 print("%d cases, %d bad, %.1f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
