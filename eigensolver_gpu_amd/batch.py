@@ -25,6 +25,9 @@ def host_threads_per_rank(cores, world):
     return max(1, min(64, int(cores) // max(int(world), 1)))
 
 
+MIN_CPUS_PER_RANK = 6   # below this share per rank, pinning would stack a rank's launch-chain threads on top of each other
+
+
 def rank_cpu_slice(cpus, local_rank, local_world):
     """The CPUs local rank `local_rank` of `local_world` ranks on one node may use: a contiguous, equal share of the sorted
     list `cpus` (the process' current affinity mask), disjoint from every other rank's.  A rank drives its GPU from a handful
@@ -34,7 +37,7 @@ def rank_cpu_slice(cpus, local_rank, local_world):
     local_world = max(1, int(local_world))
     local_rank = int(local_rank) % local_world
     per = len(cpus) // local_world
-    if per < 1:                      # fewer CPUs than ranks: everybody keeps the whole mask
+    if per < MIN_CPUS_PER_RANK:      # a share too small for a rank's own threads (four launch chains + the caller): nobody is restricted
         return cpus
     return cpus[local_rank * per:(local_rank + 1) * per]
 

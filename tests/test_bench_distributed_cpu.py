@@ -24,14 +24,16 @@ SCRIPT = textwrap.dedent("""
     r, w = dist.get_rank(), dist.get_world_size()
     masks = [None] * w
     dist.all_gather_object(masks, (before, mask))
-    if len(before) >= w:                      # enough CPUs: equal, disjoint, contiguous shares of the common mask
+    from eigensolver_gpu_amd.batch import MIN_CPUS_PER_RANK
+    if len(before) // w >= MIN_CPUS_PER_RANK:   # enough CPUs: equal, disjoint, contiguous shares of the common mask
         assert all(b == before for b, _ in masks)
         assert all(len(mk) == len(before) // w for _, mk in masks)
         allc = sum((mk for _, mk in masks), [])
         assert len(allc) == len(set(allc)), "rank CPU masks overlap"
         assert mask == rank_cpu_slice(before, lr, lw)
-    else:                                     # fewer CPUs than ranks: nobody is restricted
+    else:                                     # a share too small for a rank's own threads: nobody is restricted
         assert mask == before
+    assert rank_cpu_slice(range(16), 1, 2) == list(range(8, 16)) and rank_cpu_slice(range(16), 1, 8) == list(range(16))
     assert rank_cpu_slice(range(256), 3, 8) == list(range(96, 128)) and rank_cpu_slice([5, 1, 3], 1, 8) == [1, 3, 5]
     NP, M = (64, 4) if w == 8 else (13, 4)          # world 8: BASELINE configs[4], 64 problems -> 8 per rank
     mine = shard_problems(NP, r, w)
