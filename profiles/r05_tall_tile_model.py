@@ -9,8 +9,8 @@ column and used for every order n <= n_map of the panel (tiles whose columns sta
   C(i, c)                              <- the column-direction sums of tile (i, c / 16), per live tile.
 Reader of row r (row block ib): Y(0 .. nr(ib) - 1, r) and C(0 .. ib, r).
 This script checks, for many (n_map, n, G), that every element of the triangle is summed exactly once in each direction; it is
-the specification the HIP code was written from.  tests/test_tile_runs_model.py runs it and compares the library's host-side
-copy of the map against it."""
+the specification the HIP code of profiles/r05_tall_tile_variant.patch was written from (variant not kept: r05_experiments.txt section 10);
+while it was in the tree a CPU test ran this model and compared the library's host-side copy of the map against it."""
 import sys
 
 HR, HC = 256, 16
