@@ -31,7 +31,13 @@ namespace eig {
 
 namespace {
 
-constexpr int LEAF = 32;
+// (leaf order, A/B'd as a compile-time variant in round 5, profiles/r05_experiments.txt section 13: 16 makes the isolated solver faster --
+//  the QL chain of a leaf is 4 x shorter, one more merge level: 3.70 -> 3.64 ms at N = 4096, 1.82 -> 1.62 at N = 2048 -- and the batch rates
+//  lower: C2 198 -> 195.5, C5 109.7 -> 108.4 problems/s, one more level of launches and one more host round trip per problem; 8 is slower everywhere)
+#ifndef EIG_DC_LEAF
+#define EIG_DC_LEAF 32
+#endif
+constexpr int LEAF = EIG_DC_LEAF;
 constexpr int MAXK_LDS = 4096;  // poles staged in LDS per merge (larger merges read global memory)
 
 // ---------------------------------------------------------------------------------------------
