@@ -663,10 +663,13 @@ int stedc_device(Ctx& c, hipStream_t st, int N, const double* d_d, const double*
                     if (m.rho * std::fabs(zz[j]) <= tol) { defl.push_back(j); continue; }
                     if (pj < 0) { pj = j; continue; }
                     double s = zz[pj], cc = zz[j];
-                    double tau = std::hypot(cc, s);
-                    double tdiff = dd[j] - dd[pj];
-                    cc /= tau; s = -s / tau;
-                    if (std::fabs(tdiff * cc * s) <= tol) {
+                    const double tdiff = dd[j] - dd[pj];
+                    // dlaed2's test |tdiff c s| <= tol with c = z_j / tau, s = -z_pj / tau, tau = hypot(z_j, z_pj), multiplied through by
+                    // tau^2: the pairs that do NOT deflate (most of them above the first levels) cost four multiplications instead of a
+                    // hypot and two divisions (the scan is sequential host time between two device round trips)
+                    if (std::fabs(tdiff * cc * s) <= tol * (cc * cc + s * s)) {
+                        const double tau = std::hypot(cc, s);
+                        cc /= tau; s = -s / tau;
                         zz[j] = tau; zz[pj] = 0.0;
                         if (coltyp[j] != coltyp[pj]) coltyp[j] = 2;
                         coltyp[pj] = 4;
