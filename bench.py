@@ -376,7 +376,7 @@ def main():
             zl = {p: workspace(0, n, k).Z for k, p in enumerate(mine)}
         elif "p" in last:
             zl = {last["p"]: workspace(0, n).Z}
-        gz = gather_eigenvectors(zl, n_total, n, m)
+        gz = gather_eigenvectors(zl, n_total, n, m, dtype=torch.complex128 if cplx else torch.float64, device=dev)
         if gz is not None:
             have = [p for p in range(n_total) if bool((gz[p] != 0).any())]
             gathered_z = {"shape": list(gz.shape), "problems_present": len(have), "bytes": gz.numel() * gz.element_size(),

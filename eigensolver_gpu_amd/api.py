@@ -39,8 +39,7 @@ EXPORTS = [
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
     "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
     "eigsolve_dstedc_device", "eigsolve_zlarft", "eigsolve_dlarft", "eigsolve_zunmtr", "eigsolve_dormtr",
-    "eigsolve_zhegvdx_batch", "eigsolve_dsygvdx_batch", "eigsolve_zgemm_probe", "eigsolve_dgemm_probe",
-    "eigsolve_debug_two_stage_model",
+    "eigsolve_zhegvdx_batch", "eigsolve_dsygvdx_batch",
 ]
 
 

@@ -43,9 +43,11 @@ def rank_cpu_slice(cpus, local_rank, local_world):
 
 
 def pin_rank_to_cpu_slice(local_rank, local_world):
-    """Restricts this process (and every thread it starts afterwards: the library's workers inherit the mask) to its
-    rank_cpu_slice.  Call before the library creates its worker threads.  Returns the CPU list now in force; a platform
-    without sched_setaffinity, or a refusal by the OS, leaves the mask alone and returns it."""
+    """Restricts EVERY thread this process has at the moment of the call (os.sched_setaffinity(0, ...) alone changes only the
+    calling thread: OpenBLAS / OpenMP pools that torch or numpy started at import would keep the node-wide mask) -- and, by
+    inheritance, every thread started afterwards (the library's batch workers) -- to this rank's rank_cpu_slice.  Call before
+    the library creates its worker threads.  Returns the CPU list now in force for the calling thread; a platform without
+    sched_setaffinity, or a refusal by the OS, leaves the mask alone and returns it."""
     import os
     if not hasattr(os, "sched_getaffinity"):
         return list(range(os.cpu_count() or 1))
@@ -55,6 +57,15 @@ def pin_rank_to_cpu_slice(local_rank, local_world):
         os.sched_setaffinity(0, want)
     except OSError:
         return cur
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = []
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, want)      # (on Linux the pid argument is a thread id)
+        except OSError:
+            pass                                 # a thread that ended in between
     return sorted(os.sched_getaffinity(0))
 
 
@@ -177,36 +188,56 @@ def gather_eigenvalues(local, n_problems, m):
     return out
 
 
-def gather_eigenvectors(local, n_problems, n, m):
+def gather_eigenvectors(local, n_problems, n, m, dtype=None, device=None):
     """Optional gather of the eigenvector blocks ("w ... and optionally Z(1:N,1:m)"), off by default in
     bench.py (--gather-z): local = {problem_id: Z} with Z the solver's output block in its device layout -- a tensor whose first
     m rows are the m eigenvectors (column-major N x m = row-major m x N) -- -> [n_problems, m, n] on rank 0 (None elsewhere).
-    One all_gather of this rank's padded [per, m, n] block plus one of the problem ids; this is the only place the batch path
-    moves bulk data between GPUs (C5: 64 x 512 x 2048 complex = 1 GiB in all, 128 MiB per rank over xGMI)."""
+    One gather (dst = rank 0) of this rank's padded [per, m, n] block plus one of the problem ids: only rank 0 allocates the
+    world-sized receive list.  This is the only place the batch path moves bulk data between GPUs (C5: 64 x 512 x 2048 complex =
+    1 GiB in all, 128 MiB per rank over xGMI).
+    dtype / device: what an EMPTY rank (n_problems < world) sends -- every rank must contribute a block of the same shape, dtype
+    and device kind.  When omitted they are agreed on with one all_gather_object (first rank that holds a block decides; a rank
+    that holds none uses its current CUDA device for a CUDA peer, the CPU otherwise)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     per = (n_problems + world - 1) // world
-    any_t = next(iter(local.values())) if local else torch.zeros((m, n), dtype=torch.float64)
-    buf = torch.zeros((per, m, n), dtype=any_t.dtype, device=any_t.device)
-    ids = torch.full((per,), -1, dtype=torch.int64, device=any_t.device)
+    any_t = next(iter(local.values())) if local else None
+    # (the decision to run the agreement collective depends on the CALLER's arguments only: every rank takes the same branch)
+    agree = dist.is_initialized() and (dtype is None or device is None)
+    dev_kind = torch.device(device).type if device is not None else None
+    if any_t is not None:
+        dtype, dev_kind, device = any_t.dtype, any_t.device.type, any_t.device
+    if agree:
+        mine = (str(any_t.dtype).replace("torch.", ""), any_t.device.type) if any_t is not None else None
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        first = next((x for x in seen if x is not None), None)
+        if first is not None and any_t is None:
+            dtype = dtype or getattr(torch, first[0])
+            dev_kind = dev_kind or first[1]
+    dtype = dtype or torch.float64
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dev_kind == "cuda" else torch.device("cpu")
+    buf = torch.zeros((per, m, n), dtype=dtype, device=device)
+    ids = torch.full((per,), -1, dtype=torch.int64, device=device)
     for k, (p, Z) in enumerate(sorted(local.items())):
         ids[k] = p
         buf[k] = Z[:m, :n]
     if dist.is_initialized():
-        idl = [torch.empty_like(ids) for _ in range(world)]
-        dist.all_gather(idl, ids)
         # (complex blocks travel as (re, im) pairs: every backend moves real tensors)
         sbuf = torch.view_as_real(buf) if buf.is_complex() else buf
-        rparts = [torch.empty_like(sbuf) for _ in range(world)]
-        dist.all_gather(rparts, sbuf)
+        idl = [torch.empty_like(ids) for _ in range(world)] if rank == 0 else None
+        rparts = [torch.empty_like(sbuf) for _ in range(world)] if rank == 0 else None
+        dist.gather(ids, idl, dst=0)
+        dist.gather(sbuf, rparts, dst=0)
+        if rank != 0:
+            return None
         parts = [torch.view_as_complex(x) if buf.is_complex() else x for x in rparts]
     else:
         parts, idl = [buf], [ids]
-    if rank != 0:
-        return None
-    out = torch.zeros((n_problems, m, n), dtype=any_t.dtype, device=any_t.device)
+    out = torch.zeros((n_problems, m, n), dtype=dtype, device=device)
     for part, pid in zip(parts, idl):
         keep = pid >= 0
         out[pid[keep]] = part[keep]

@@ -122,7 +122,9 @@ template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda
 template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, const T* U, int ldu);
 
 // launch skeleton of stage 1 of a two-stage reduction (timing only; see blas3.hip)
+#ifdef EIG_TOOLS
 template <class T> void two_stage_stage1_skeleton(Ctx& c, hipStream_t st, int N, int what);
+#endif
 
 inline constexpr int kDiagBlk = 64;  // order of the inverted diagonal blocks
 

@@ -1927,10 +1927,17 @@ template <class T> static void hegst_pregrow(Ctx& c, int N) {
         const int nb = gran < 256 ? 256 : gran;
         qT = (size_t)nb * N; qH = (size_t)nb * nb; qF = (size_t)nb * nb;
     } else if (c.gst_mode == 0 || N < 256) {
-        if (N > DB) {                              // (orders up to 64 are one block: no block step)
-            const int n1 = split_n1(N);
-            qT = (size_t)n1 * (N - n1) + 64; qH = (size_t)n1 * n1;
-        }
+        // (orders up to 64 are one block: no block step.  Every level of hegst_rec is walked: N = 129 splits 128 + 1 at the top
+        //  -- T is 128 x 1 -- and 64 + 64 one level down, where T is 64 x 64)
+        std::function<void(int)> walk = [&](int n) {
+            if (n <= DB) return;
+            const int n1 = split_n1(n), n2 = n - n1;
+            qT = std::max(qT, (size_t)n1 * n2 + 64);
+            qH = std::max(qH, (size_t)n1 * n1);
+            walk(n1);
+            walk(n2);
+        };
+        walk(N);
     } else {
         qF = (size_t)N * N;
     }
@@ -2035,6 +2042,7 @@ template <class T> void hegst_pipelined_finish(Ctx& c, int N, T* A, int lda, con
     EIG_HIP(hipStreamWaitEvent(c.s1, c.evB, 0));
 }
 
+#ifdef EIG_TOOLS   // experiment code: only in the tools-side build (make tools), never in libeigsolve_gpu.so
 // ---- two-stage reduction, stage 1 (full -> band of width b = 64): LAUNCH SKELETON for the go / no-go measurement ----------------
 // VERDICT r4 item 3 asks for a stage-1 spike with a kill criterion (C3 > 15 ms or C4 > 100 ms => stop).  Before building the
 // numerics this routine issues the complete launch sequence stage 1 would consist of -- every product with its true shape, operand
@@ -2116,6 +2124,7 @@ template <class T> void two_stage_stage1_skeleton(Ctx& c, hipStream_t st, int N,
 }
 template void two_stage_stage1_skeleton<cplx>(Ctx&, hipStream_t, int, int);
 template void two_stage_stage1_skeleton<double>(Ctx&, hipStream_t, int, int);
+#endif  // EIG_TOOLS
 
 // explicit instantiations
 #define INST(T)                                                                                                          \

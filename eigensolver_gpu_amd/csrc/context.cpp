@@ -101,35 +101,33 @@ void try_roctx() {
 }
 }  // namespace
 
-void* Ctx::scratch_bytes(const char* name, size_t bytes) {
-    auto& s = slots[name];
+// may_fail: "not enough device memory" is an answer (nullptr; the slot is then empty, nothing is printed), not an exception
+static void* scratch_grow(Ctx& c, const char* name, size_t bytes, bool may_fail) {
+    auto& s = c.slots[name];
     if (s.second < bytes) {
         if (s.first) {
-            if (lease_depth > 0) sync(s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
-            if (s2) EIG_HIP(hipStreamSynchronize(s2));
+            if (c.lease_depth > 0) c.sync(c.s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
+            if (c.s2) EIG_HIP(hipStreamSynchronize(c.s2));
             void* old = s.first;
             s.first = nullptr; s.second = 0;   // (a failing hipMalloc below must not leave a dangling pointer in the slot)
             EIG_HIP(hipFree(old));
         }
-        size_t cap = bytes + bytes / 8 + 256;
-        EIG_HIP(hipMalloc(&s.first, cap));
+        const size_t cap = bytes + bytes / 8 + 256;
+        const hipError_t e = hipMalloc(&s.first, cap);
+        if (e != hipSuccess) {
+            s.first = nullptr; s.second = 0;
+            if (may_fail && (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation)) {
+                (void)hipGetLastError();       // (handled: clear the sticky error, print nothing)
+                return nullptr;
+            }
+            EIG_HIP(e);
+        }
         s.second = cap;
     }
     return s.first;
 }
-
-// like scratch_bytes, but "not enough device memory" is an answer (nullptr; the slot is then empty), not an exception
-void* Ctx::try_scratch_bytes(const char* name, size_t bytes) {
-    try {
-        return scratch_bytes(name, bytes);
-    } catch (const HipFail& f) {
-        if (f.err != hipErrorOutOfMemory && f.err != hipErrorMemoryAllocation) throw;
-        (void)hipGetLastError();
-        auto& s = slots[name];
-        s.first = nullptr; s.second = 0;
-        return nullptr;
-    }
-}
+void* Ctx::scratch_bytes(const char* name, size_t bytes) { return scratch_grow(*this, name, bytes, false); }
+void* Ctx::try_scratch_bytes(const char* name, size_t bytes) { return scratch_grow(*this, name, bytes, true); }
 
 void* Ctx::host_scratch_bytes(const char* name, size_t bytes) {
     auto& s = hslots[name];

@@ -1041,6 +1041,7 @@ int eigsolve_dgemm_bench(char ta, char tb, int M, int N, int K, const double* A_
     return gemm_bench_entry<double>(ta, tb, M, N, K, A_d, lda, B_d, ldb, C_d, ldc, reps, ms_avg);
 }
 
+#ifdef EIG_TOOLS   // experiment hooks: only in the tools-side build (make -C eigensolver_gpu_amd/csrc tools; tools/eigsolve_tools.h)
 // experiment hook (tools/gemm_shapes.py): like ?gemm_bench with beta = 1 and/or operand masks (enum Mask, stored coordinates)
 template <class T>
 static int gemm_probe_entry(char ta, char tb, int M, int N, int K, const T* A, int lda, const T* B, int ldb, T* C, int ldc,
@@ -1074,6 +1075,7 @@ extern "C" int eigsolve_debug_two_stage_model(int N, int cplx_, int what, int re
         return bench_loop<double>(c, reps, ms_avg, [&]() { two_stage_stage1_skeleton<double>(c, c.s1, N, what); });
     });
 }
+#endif  // EIG_TOOLS
 
 template <class T> static int her2k_entry(int n, int k, const T* V, int ldv, const T* W, int ldw, T* C, int ldc, int reps, double* ms) {
     return guarded(nullptr, [&]() -> int {

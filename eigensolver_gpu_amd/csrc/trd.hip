@@ -296,10 +296,6 @@ extern "C" int eigsolve_debug_trd_timing(unsigned long long* out36) {
 // Grid = [gemv workgroups | hemv workgroups]: the (short, latency-bound) gemv items start first
 // and hide under the bandwidth-bound tiles.  Loads are issued before the scalar prologue.
 // ------------------------------------------------------------------------------------------
-#ifndef EIG_MV_SKIP
-#define EIG_MV_SKIP 0     // (timing variants of panel_mv_kernel: bit 0 no cross-lane column reduction, bit 1 no products, bit 2 no partial-sum
-                          //  stores -- wrong results, same tile loads)
-#endif
 __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
     // t = J(J+1)/2 + I, I <= J.  Single-precision estimate (one v_sqrt_f32) + exact integer correction.
     J = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
@@ -380,10 +376,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
             // 8 columns at a time: products, then the first two levels of the column reduction
             auto half = [&](int jb, T& w0, T& w1) {
                 T tj[8];
-                if (EIG_MV_SKIP & 2) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { yI = yI + av[jb + j]; tj[j] = av[jb + j]; }
-                } else if (interior) {
+                if (interior) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         fma_(yI, av[jb + j], xcs[xs][wave * 16 + jb + j]);
@@ -405,13 +398,12 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
                         tj[j] = p;
                     }
                 }
-                if (EIG_MV_SKIP & 1) { w0 = (tj[0] + tj[1]) + (tj[2] + tj[3]); w1 = (tj[4] + tj[5]) + (tj[6] + tj[7]); }
-                else transpose_reduce8_phase1<T>(tj, w0, w1);
+                transpose_reduce8_phase1<T>(tj, w0, w1);
             };
             T wa0, wa1, wb0, wb1;
             half(0, wa0, wa1);
             half(8, wb0, wb1);
-            const T tval = (EIG_MV_SKIP & 1) ? (wa0 + wa1) + (wb0 + wb1) : transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
+            const T tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
             TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
             redy[rb][wave][lane] = yI;
             if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
@@ -519,10 +511,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         T tv = scale * redt[rb][lane];
         T vI = scale * xr + unit(r0 + lane);
         T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
-        if (EIG_MV_SKIP & 4) {
-            fmac_(Sacc, vI, yv);
-            fmac_(Sacc, vJ, tv);
-        } else if (diag) {
+        if (diag) {
             T s = yv + tv;
             a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
             fmac_(Sacc, vI, s);

@@ -75,15 +75,17 @@ int eigsolve_set_host_threads(int nthreads);
  *   "graph"     1 = the tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working
  *               copy of A and replayed as a hipGraph; 0 (default) = eager launches (measured neutral).
  *   "tile_map"  1 (default) = XCD-aware super-tile order of the MFMA engine's workgroups, 0 = plain grids (A/B measurements).
- *   "hemv_blocks" workgroups of the panel mat-vec kernel (0 = automatic: one per CU for a solve that has the device to itself,
- *               3/4 of the CUs inside a batch call).
+ *   "hemv_blocks" workgroups of the panel mat-vec kernel (0 = automatic: one workgroup per CU, in every mode -- a grid that depended
+ *               on the mode would change the order of the partial sums and with it the bit-identity of batch and single solves).
  *   "trace_marks" 1 = marker kernels at the phase boundaries (segments a rocprofv3 kernel trace, tools/trace_phases.py).
  *   "zs_cap_mb" largest library-side copy (MiB, default 4096) of the standard problem's eigenvectors the generalized drivers keep:
  *               they form those N x m vectors in library scratch (sizeof(T) N m bytes of device memory per context on top of the
  *               caller's buffers: 64 MiB at C3, 1 GiB at C4 full spectrum; every worker context of a batch call has its own) and the
  *               final triangular solve writes the caller's Z once.  Above the cap, or when the device cannot provide the block, the
  *               vectors are formed in the caller's Z (as the reference does) and the solve runs in column chunks through a smaller
- *               block -- same results to rounding.
+ *               block -- same results to rounding.  Scope: eigsolve_?hegvdx and the problems a batch call solves one per launch
+ *               chain; the LOCKSTEP groups of a batch call (small orders, "batch_fuse" > 1 or "batch_workers" = 0: a matrix of
+ *               at most 96 MiB in the automatic setting) and the stage-level eigsolve_?trsm_lun always keep the full block.
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 
@@ -222,19 +224,6 @@ int eigsolve_zgemm_bench(char ta, char tb, int M, int N, int K, const void *A_d,
                          void *C_d, int ldc, int reps, double *ms_avg);
 int eigsolve_dgemm_bench(char ta, char tb, int M, int N, int K, const double *A_d, int lda, const double *B_d,
                          int ldb, double *C_d, int ldc, int reps, double *ms_avg);
-
-/* Experiment hooks (tools/gemm_shapes.py, tools/dgemm_shapes.py, tools/two_stage_model.py; not part of the reference's interface):
- * ?gemm_probe = ?gemm_bench with beta = 1 when beta_one != 0 and operand masks (0 none, 1 upper, 2 strictly upper, 3 lower,
- * 4 unit trapezoid with offset moff, in stored coordinates) -- the forms the solve's triangular / trapezoidal products take;
- * debug_two_stage_model times the launch skeleton of stage 1 of a two-stage reduction (full -> band 64) of order N on
- * pseudo-random data (what: 0 whole stage, 1 panels only, 2 trailing updates only): the go / no-go measurement of round 5. */
-int eigsolve_zgemm_probe(char ta, char tb, int M, int N, int K, const void *A_d, int lda, const void *B_d, int ldb,
-                         void *C_d, int ldc, int reps, int beta_one, int maskA, int moffA, int maskB, int moffB,
-                         double *ms_avg);
-int eigsolve_dgemm_probe(char ta, char tb, int M, int N, int K, const double *A_d, int lda, const double *B_d,
-                         int ldb, double *C_d, int ldc, int reps, int beta_one, int maskA, int moffA, int maskB,
-                         int moffB, double *ms_avg);
-int eigsolve_debug_two_stage_model(int N, int cplx, int what, int reps, double *ms_avg);
 
 /* her2k/syr2k, uplo='U', trans='N': C <- C - V W^H - W V^H (the trd trailing update,
  * zhetrd_gpu.F90:67,82).  C n x n, V,W n x k. */

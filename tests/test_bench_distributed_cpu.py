@@ -88,6 +88,14 @@ SCRIPT = textwrap.dedent("""
             assert torch.equal(gz[p], zblock(p)[:MZ]), p
     else:
         assert gz is None
+    # a rank WITHOUT a block (n_problems < world) still contributes one of the right shape, dtype and device kind
+    g1 = gather_eigenvectors({0: zblock(0)} if r == 0 else {}, 1, NZ, MZ)
+    g2 = gather_eigenvectors({0: zblock(0)} if r == w - 1 else {}, 1, NZ, MZ, dtype=torch.complex128, device="cpu")
+    if r == 0:
+        assert g1.shape == (1, MZ, NZ) and g1.dtype == torch.complex128 and torch.equal(g1[0], zblock(0)[:MZ])
+        assert g2.shape == (1, MZ, NZ) and torch.equal(g2[0], zblock(0)[:MZ])
+    else:
+        assert g1 is None and g2 is None
     t = torch.tensor([1.0 + r], dtype=torch.float64)
     allt = [torch.empty_like(t) for _ in range(w)]
     dist.all_gather(allt, t)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Single-launch rate of the mat-vec kernel (plain hemv mode) at a few orders + the sweep of one tridiagonalization.
-With EIGSOLVE_GPU_LIB pointing at a -DEIG_MV_SKIP=n build (make OUTDIR=../lib/v_mvN EXTRA=-DEIG_MV_SKIP=N) this attributes the
-time of a tile: 1 = no cross-lane column reduction, 2 = no products (results are wrong by construction; the loads are the same).
+EIGSOLVE_GPU_LIB selects a compile-time variant build for A/B runs (make OUTDIR=../lib/v_x EXTRA=-D...); EIGSOLVE_MV_DMA=0/1 the
+data path of the kernel (registers / LDS-DMA ring).
 Usage: python tools/hemv_rate.py [N ...]"""
 import os
 import sys

@@ -10,6 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _toolslib  # noqa: E402,F401  (tools-side build of the library: EIG_TOOLS hooks)
 import torch  # noqa: E402
 from eigensolver_gpu_amd import api  # noqa: E402
 
