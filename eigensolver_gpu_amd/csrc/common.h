@@ -132,6 +132,7 @@ constexpr int kGstThrDefault = 1024;
 // factorization) or 256 (merged after it, build_inv256 in blas3.hip)
 constexpr int kTrsmBaseDefault = 256;
 inline int norm_trsm_base(int v) { return v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 64)); }
+constexpr int kMvDmaDefault = 0;   // (set from the measurements of round 6, profiles/r06_experiments.txt)
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;
 
@@ -155,6 +156,8 @@ struct Ctx {
     int trd_nb = kTrdNbDefault;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
+    int mv_dma = kMvDmaDefault;   // smallest trailing order for which the panel mat-vec streams its tiles through the LDS-DMA ring
+                             // (panel_mv_kernel<T, NB, true> in trd.hip); 0 = never (the register-staged form everywhere)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");
                              // measured neutral on MI355X/ROCm 7.2 (dispatch latency is device-side), so off by default
     int in_batch = 0;        // set while this context solves one problem of a batch call with several problems in flight

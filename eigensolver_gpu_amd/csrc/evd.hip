@@ -296,7 +296,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
         (void)hemv_scratch_touch<T>(c, N, cur + 5);   // all scratch used inside the captured region exists before capture
         cur[0] = Aw; cur[1] = Ww; cur[2] = tauw; cur[3] = dw; cur[4] = ew;
         char key[64];
-        snprintf(key, sizeof key, "trd_%c_%d_%d_%d_%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks, c.trd_finish);   // everything the captured launch sequence bakes in
+        snprintf(key, sizeof key, "trd_%c_%d_%d_%d_%d_%d", Tr<T>::cx ? 'z' : 'd', N, c.trd_nb, c.hemv_blocks, c.trd_finish, c.mv_dma);   // everything the captured launch sequence bakes in
         Ctx::GraphEntry& ge = c.graphs[key];
         bool valid = ge.exec != nullptr;
         for (int q = 0; q < 16 && valid; ++q) valid = (ge.ptrs[q] == cur[q]);

@@ -36,8 +36,13 @@ namespace eig {
 __device__ unsigned long long g_trd_stamp[4][16];   // [kernel][phase] accumulated shader cycles, block 0 lane 0
 __device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel, 1: panel_row_kernel
 #define TSTAMP(KID, PH, T0) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
+#define TSTAMPW(KID, PH, T0, W) do { if (blockIdx.x == 0 && threadIdx.x == 64 * (W)) atomicAdd(&g_trd_stamp[KID][PH], (unsigned long long)(__builtin_readcyclecounter() - (T0))); } while (0)
 #else
 #define TSTAMP(KID, PH, T0) do { } while (0)
+#define TSTAMPW(KID, PH, T0, W) do { } while (0)
+#endif
+#ifndef EIG_MV_PADLDS
+#define EIG_MV_PADLDS 0   // (measurement variant: the register-staged kernel with the LDS footprint of the DMA form)
 #endif
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
@@ -304,32 +309,136 @@ __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
     I = t - J * (J + 1) / 2;
 }
 
-template <class T, int NB>
-__global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, int plain, int gg) {
+// ---- LDS-DMA (global_load_lds_dwordx4) -------------------------------------------------------------------------------------
+// One wave instruction copies 64 x 16 B straight from global memory into LDS at [M0 base + 16 * lane]: no VGPR destination, so the
+// number of bytes a wave keeps in flight is bounded by the LDS it owns, not by its registers (MI355X_MICROARCH.md, "LDS-DMA").
+// hipcc does not count these operations (cdna_hip_programming.md 5.7): completion is waited for with explicit s_waitcnt vmcnt(N),
+// and a wave that uses them issues NO other vector-memory loads, so the counts below are exact.  M0 is saved and restored around
+// the instruction (it is compiler-reserved).
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(uintptr_t)p; }   // low half of the flat address
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_wave_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_uniform)
+                 : "memory");
+}
+// NI instructions of one slot in ONE statement (M0 saved once): instruction q copies [base + voff + q * stride] -> [dst + 1024 q].
+// base, stride, dst wave-uniform; voff = the lane's byte offset.  Three instructions per piece: the M0 update, the offset update
+// (which also is the wait state an M0 write needs in front of an LDS-DMA) and the copy.
+#define EIG_DMA_STEP "global_load_lds_dwordx4 %1, %2\n\ts_add_u32 m0, m0, 0x400\n\tv_add_u32 %1, %3, %1\n\t"
+#define EIG_DMA_STEP4 EIG_DMA_STEP EIG_DMA_STEP EIG_DMA_STEP EIG_DMA_STEP
+template <int NI> __device__ __forceinline__ void lds_dma16_run(const void* base, unsigned voff, unsigned stride, unsigned dst) {
+    static_assert(NI == 8 || NI == 16, "pieces per slot");
+    unsigned keep;
+    if constexpr (NI == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t" EIG_DMA_STEP4 EIG_DMA_STEP4 EIG_DMA_STEP4 EIG_DMA_STEP4 "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(voff)
+                     : "s"(base), "s"(stride), "s"(dst)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t" EIG_DMA_STEP4 EIG_DMA_STEP4 "s_mov_b32 m0, %0"
+                     : "=&s"(keep), "+v"(voff)
+                     : "s"(base), "s"(stride), "s"(dst)
+                     : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Geometry of the LDS ring of panel_mv_kernel<T, NB, true>: every streaming wave owns DEPTH slots; a slot holds the wave's 16
+// columns of one 64 x 64 tile ([column][64 rows], exactly the image the DMA writes: a column of 64 complex numbers is one
+// instruction, two columns of 64 doubles are one) followed by the tile's 64 column entries and 64 row entries of v.
+constexpr int MVD = 384;   // four streaming waves + the finishing wave + the wave of the stacked products
+template <class T> struct MvRing {
+    static constexpr int ES = (int)sizeof(T);
+    static constexpr int CPI = 1024 / (HT * ES);        // tile columns per DMA instruction: 1 (complex) / 2 (real)
+    static constexpr int NDA = 16 / CPI;                // instructions per slot for the matrix
+    static constexpr int NDV = Tr<T>::cx ? 2 : 1;       // ... for the entries of v
+    static constexpr int NDT = NDA + NDV;
+    static constexpr int DEPTH = Tr<T>::cx ? 2 : 4;     // slots (wave-tiles in flight) per streaming wave
+    static constexpr int SLOT = 18 * HT * ES;           // bytes
+    static constexpr int RING = 4 * DEPTH * SLOT;       // 144 KB
+    static constexpr int REDY = RING, REDT = REDY + 2 * 4 * HT * ES, XCS = REDT + 2 * HT * ES, TOTAL = XCS + 3 * HT * ES;
+    static_assert(TOTAL <= 160 * 1024, "one workgroup per CU");
+};
+
+// The products of one 64 x 64 tile for the wave that holds 16 of its columns (av[j] = A(r, c0 + 16 wave + j), one row per lane):
+// yI = sum_j A(r, c) xc(c) (this wave's part of the row-direction sum) and tval = the 64-lane sum of conj(A(r, c)) xr for the column
+// transpose_col_of_lane(lane) -- 8 columns at a time: products, then the first two levels of the column reduction.  Shared by the
+// register-staged and the LDS-DMA data path (panel_mv_kernel / panel_mv_dma_kernel): same operations in the same order, i.e. the
+// two kernels give bit-identical results.
+template <class T, class XC>
+__device__ __forceinline__ void mv_tile_products(const T (&av)[16], T xr, XC xc, int wave, int lane, int r, int c0, int n, bool diag,
+                                                 bool interior, T& yI, T& tval) {   // xc(j) = entry of v for the wave's column j
+    const T zero = Tr<T>::zero();
+    yI = zero;
+    auto half = [&](int jb, T& w0, T& w1) {
+        T tj[8];
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                fma_(yI, av[jb + j], xc(jb + j));
+                T p = Tr<T>::zero();
+                fmac_(p, av[jb + j], xr);
+                tj[j] = p;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int cc = c0 + wave * 16 + jb + j;
+                const bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
+                const bool dg = diag && r == cc;
+                T v = sel(ok, av[jb + j], zero);
+                v = sel(dg, Tr<T>::realpart(v), v);
+                fma_(yI, v, xc(jb + j));
+                T p = Tr<T>::zero();
+                fmac_(p, sel(dg, zero, v), xr);
+                tj[j] = p;
+            }
+        }
+        transpose_reduce8_phase1<T>(tj, w0, w1);
+    };
+    T wa0, wa1, wb0, wb1;
+    half(0, wa0, wa1);
+    half(8, wb0, wb1);
+    tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
+}
+
+template <class T, int NB, bool DMA>
+__global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(PanelBatch<T, NB> ab, int plain, int gg) {
     const PanelArgs<T>& a = ab.p[NB == 1 ? 0 : blockIdx.y];
     const int i = a.i, n = i;  // v has n entries (rows 0..i-1), v(n-1) = 1
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (DMA form: the wave index is made wave-uniform FOR THE COMPILER, so that the wave roles below are scalar branches.  With a
+    //  per-lane condition hipcc lays the roles out one after the other under exec masks and its s_waitcnt bookkeeping flows from
+    //  one role into the next: the streaming waves then waited vmcnt(12) in front of their LDS reads -- for registers the OTHER
+    //  roles load into -- which drains the DMA ring every tile.)
+    const int tid = threadIdx.x, lane = tid & 63, wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
 #if EIG_TRD_TIMING
     const long long T0 = __builtin_readcyclecounter();
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trd_count[0], 1ULL);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&g_trd_count[0], 1ULL); atomicAdd(&g_trd_count[2], 1ULL); }
 #endif
     // Five waves: 0-3 stream and multiply the tiles, wave 4 evaluates the larfg scalars (a serial chain of ~1500 cycles)
     // while the first tile is being multiplied and finishes every tile (partial sums, S, the stored v) while the
     // others are already on the next one.  LDS hand-over buffers are double (partials) / triple (column entries of
     // v) buffered so that one barrier per tile is enough.  Two workgroups per CU need <= 168 VGPRs per wave (10 waves
     // on 4 SIMDs): the column reduction runs in two halves of 8 columns to stay below that.
-    __shared__ T redy[2][4][64];
-    __shared__ T redt[2][64];
-    __shared__ T xcs[3][HT];   // xh entries of the tile columns: tile k of this workgroup uses slot k % 3
+    // (ONE LDS object: a second one makes hipcc wait vmcnt(0) in front of LDS reads, cdna_hip_programming.md 5 "three traps")
+    using RG = MvRing<T>;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(DMA || EIG_MV_PADLDS) ? RG::TOTAL : RG::TOTAL - RG::RING];
+    constexpr int SM0 = DMA ? RG::RING : 0;
+    T (&redy)[2][4][64] = *reinterpret_cast<T (*)[2][4][64]>(smem + SM0);
+    T (&redt)[2][64] = *reinterpret_cast<T (*)[2][64]>(smem + SM0 + (RG::REDT - RG::REDY));
+    T (&xcs)[3][HT] = *reinterpret_cast<T (*)[3][HT]>(smem + SM0 + (RG::XCS - RG::REDY));   // xh entries of the tile columns: tile k of this workgroup uses slot k % 3
     constexpr int NPL = 16;    // norm partials per lane loaded up front (N <= 4096 without the tail loop)
     // The mat-vec workgroups come FIRST in the grid: tile t is then always taken by workgroup t mod gh, i.e. (gh = one per CU, a
     // multiple of 8) by the same XCD in every column of the sweep, and what that XCD's L2 still holds of the tile from the previous
     // column is a hit -- the whole stored triangle once it is below 8 x 4 MB (round 4: zhetrd N=2048 21.2 -> 20.2 ms, dsytrd
     // N=2048 17.0 -> 16.8, zhetrd N=4096 66.6 -> 66.2; with the gemv workgroups in front the XCD of a tile moved with their count).
-    const bool is_gemv = (int)blockIdx.x >= a.gh;
+    // DMA form: no separate workgroups for the stacked products (a workgroup holds the whole LDS of its CU, the short ones could
+    // not start beside the streaming ones): wave 5 of every mat-vec workgroup takes the items hb, hb + gh, ... and exits.
+    const bool is_gemv = DMA ? wave == 5 : (int)blockIdx.x >= a.gh;
     const int hb = (int)blockIdx.x;          // hemv workgroup index
     const int gb = (int)blockIdx.x - a.gh;   // gemv workgroup index
-    if (is_gemv && wave == 4) return;
+    if (!DMA && is_gemv && wave == 4) return;
 
     // v = scale * xh + e_(n-1), xh = raw column with the entries >= nz zeroed.  Everything below is linear in
     // v, so the products are formed with xh (known at launch) and the larfg scalars -- the end of a chain
@@ -343,7 +452,106 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     const int nt = (n + HT - 1) / HT;
     const int ntiles = nt * (nt + 1) / 2;
     int I = 0, J = 0, t = hb;
-    if (!is_gemv && wave < 4) {
+    if constexpr (DMA) {
+        if (wave < 4) {
+            // Streaming waves, LDS-DMA form: DEPTH wave-tiles in flight per wave whatever the wave computes meanwhile.  Per tile:
+            // wait for its slot (the younger tiles' instructions stay in flight), copy the slot into registers, hand the slot straight
+            // back to the DMA for the tile DEPTH steps ahead, and only then multiply -- the memory pipe never waits for the products.
+            constexpr int DEPTH = RG::DEPTH, ES = RG::ES;
+            const int wu = wave;
+            const unsigned ring_w = lds_offset_of(smem) + (unsigned)(wu * DEPTH * RG::SLOT);
+            const int vcl = max(nz - 1, 0);
+            auto issue = [&](int slot, int tt) {
+                int Iq, Jq;
+                tile_decode(tt, Iq, Jq);
+                const int r0 = Iq * HT, c0 = Jq * HT;
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring_w + (unsigned)(slot * RG::SLOT)));
+                // interior tile (every row and column inside the matrix): the columns are lda apart -> one statement, 3 instructions
+                // per piece instead of a 64-bit address computation each
+                const bool inside = r0 + HT <= n && c0 + HT <= n && (long)a.lda * ES * 16 < (1L << 31);
+                if (inside) {
+                    if constexpr (Tr<T>::cx) {
+                        lds_dma16(a.xbuf + min(c0 + lane, vcl), dst + 16 * HT * ES);
+                        lds_dma16(a.xbuf + min(r0 + lane, vcl), dst + 17 * HT * ES);
+                        lds_dma16_run<16>(a.A + (size_t)r0 + (size_t)(c0 + wu * 16) * a.lda, (unsigned)(lane * ES), (unsigned)(a.lda * ES), dst);
+                    } else {
+                        const int l2 = 2 * (lane & 31), hi = lane >> 5;
+                        lds_dma16(a.xbuf + (hi ? r0 + l2 : c0 + l2), dst + 16 * HT * ES);
+                        lds_dma16_run<8>(a.A + (size_t)r0 + (size_t)(c0 + wu * 16) * a.lda, (unsigned)(l2 * ES + hi * a.lda * ES),
+                                         (unsigned)(2 * a.lda * ES), dst);
+                    }
+                    return;
+                }
+                if constexpr (Tr<T>::cx) {
+                    lds_dma16(a.xbuf + min(c0 + lane, vcl), dst + 16 * HT * ES);
+                    lds_dma16(a.xbuf + min(r0 + lane, vcl), dst + 17 * HT * ES);
+                    const size_t roff = (size_t)min(r0 + lane, n - 1);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        lds_dma16(a.A + roff + (size_t)min(c0 + wu * 16 + q, n - 1) * a.lda, dst + q * 1024);
+                } else {
+                    // 16 B = two consecutive rows; lanes 0-31 / 32-63 = two consecutive columns (v: column entries / row entries).
+                    // Raw, clamped pairs: everything beyond n or nz is masked when the tile is consumed.  (lda even, A and xbuf
+                    // 16-byte aligned: checked by the host; xbuf is the library's own buffer of nt * 64 + 64 entries.)
+                    const int l2 = 2 * (lane & 31), hi = lane >> 5;
+                    lds_dma16(a.xbuf + (hi ? r0 + l2 : c0 + l2), dst + 16 * HT * ES);
+                    const size_t roff = (size_t)min(r0 + l2, (n - 1) & ~1);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        lds_dma16(a.A + roff + (size_t)min(c0 + wu * 16 + 2 * q + hi, n - 1) * a.lda, dst + q * 1024);
+                }
+            };
+            // (Measured and dropped: a barrier here, so that the loads of the finishing wave and of the stacked products are queued
+            //  in front of the tile pieces -- a CU serves its vector-memory requests in order and behind 72 KB of pieces the stacked
+            //  products' loads come back after 9000 cycles.  The barrier costs the tiles 1400 cycles and the launch 0.3 us:
+            //  profiles/r06_experiments.txt section 1.)
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d)
+                if (t + d * a.gh < ntiles) issue(d, t + d * a.gh);
+            TSTAMP(0, 0, T0);   // first DEPTH tiles requested
+            int k = 0;
+            while (t < ntiles) {
+                tile_decode(t, I, J);
+                const int r0 = I * HT, c0 = J * HT;
+                const bool diag = (I == J);
+                const int r = r0 + lane;
+                const int rb = k & 1, xs = k % 3, slot = k & (DEPTH - 1);
+                const int ahead = min(DEPTH - 1, (ntiles - 1 - t) / a.gh);   // younger tiles of this wave in flight
+                if (ahead == 0) wait_vmcnt<0>();
+                else if (ahead == 1) wait_vmcnt<RG::NDT>();
+                else if (ahead == 2) wait_vmcnt<2 * RG::NDT>();
+                else wait_vmcnt<3 * RG::NDT>();
+                if (k == 0) TSTAMP(0, 1, T0);   // first tile landed
+                const T* sp = reinterpret_cast<const T*>(smem + (wu * DEPTH + slot) * RG::SLOT);
+                T av[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) av[j] = sp[j * HT + lane];
+                const T xc_raw = sp[16 * HT + lane], xr_raw = sp[17 * HT + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is in registers: it may be overwritten
+                if (k == 0) TSTAMP(0, 6, T0);   // ... and copied into registers
+                if (t + DEPTH * a.gh < ntiles) issue(slot, t + DEPTH * a.gh);
+                if (k == 0) TSTAMP(0, 7, T0);   // ... slot handed back to the DMA
+                xcs[xs][lane] = sel(c0 + lane < nz, xc_raw, zero);
+                const T xr = sel(r < nz, xr_raw, zero);
+                const bool interior = !diag && r0 + HT <= n && c0 + HT <= n;
+                T yI, tval;
+                T xcv[16];      // the wave's 16 column entries of v: all LDS reads in flight at once, not one round trip per column
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xcv[j] = xcs[xs][wave * 16 + j];
+                mv_tile_products<T>(av, xr, [&](int j) -> T { return xcv[j]; }, wave, lane, r, c0, n, diag, interior, yI, tval);
+                if (k == 0) { TSTAMP(0, 3, T0); TSTAMPW(2, 0, T0, 3); }   // first tile multiplied: wave 0, wave 3
+                redy[rb][wave][lane] = yI;
+                if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
+                t += a.gh;
+                ++k;
+                __syncthreads();
+                if (k == 1) TSTAMP(2, 1, T0);   // first barrier passed (streaming wave 0)
+            }
+            TSTAMP(2, 2, T0);   // streaming wave 0 done
+            return;
+        }
+    }
+    if (!DMA && !is_gemv && wave < 4) {
         T av[16], xr_raw = zero;   // raw loads of the tile in flight
         // Issue the loads of tile t: unconditional, clamped addresses, nothing else in between (a select on a
         // loaded value is where the compiler waits; masks are applied when the tile is consumed).  The column
@@ -372,38 +580,8 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
             const int rb = k & 1, xs = k % 3;
             const T xr = sel(r < nz, xr_raw, zero);
             const bool interior = !diag && r0 + HT <= n && c0 + HT <= n;
-            T yI = Tr<T>::zero();
-            // 8 columns at a time: products, then the first two levels of the column reduction
-            auto half = [&](int jb, T& w0, T& w1) {
-                T tj[8];
-                if (interior) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        fma_(yI, av[jb + j], xcs[xs][wave * 16 + jb + j]);
-                        T p = Tr<T>::zero();
-                        fmac_(p, av[jb + j], xr);
-                        tj[j] = p;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int cc = c0 + wave * 16 + jb + j;
-                        const bool ok = (r < n) && (cc < n) && (!diag || r <= cc);
-                        const bool dg = diag && r == cc;
-                        T v = sel(ok, av[jb + j], zero);
-                        v = sel(dg, Tr<T>::realpart(v), v);
-                        fma_(yI, v, xcs[xs][wave * 16 + jb + j]);
-                        T p = Tr<T>::zero();
-                        fmac_(p, sel(dg, zero, v), xr);
-                        tj[j] = p;
-                    }
-                }
-                transpose_reduce8_phase1<T>(tj, w0, w1);
-            };
-            T wa0, wa1, wb0, wb1;
-            half(0, wa0, wa1);
-            half(8, wb0, wb1);
-            const T tval = transpose_reduce_phase2<T>(wa0, wa1, wb0, wb1, lane);
+            T yI, tval;
+            mv_tile_products<T>(av, xr, [&](int j) -> T { return xcs[xs][wave * 16 + j]; }, wave, lane, r, c0, n, diag, interior, yI, tval);
             TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
             redy[rb][wave][lane] = yI;
             if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
@@ -412,7 +590,9 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
             if (t < ntiles) issue_tile(k % 3);   // next tile's loads fly while wave 4 finishes this one
             TSTAMP(0, 4, T0);
             __syncthreads();
+            if (k == 1) TSTAMP(2, 1, T0);
         }
+        TSTAMP(2, 2, T0);
         return;
     }
 
@@ -449,35 +629,41 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
 
     if (is_gemv) {
         // stacked conjugate-transposed products z1 = V^H v, z2 = W^H v (partials per row chunk), one item per wave
+        // (DMA form: wave 5 of workgroup hb takes the items hb, hb + gh, ...; the larfg scalars are derived once)
         const int npo = a.np - 1 - i;
         const int wbase = a.np - a.nb;
-        const int item = gb * 4 + wave;
-        if (item >= 2 * npo * a.nchunk) return;
-        const int ch = item / (2 * npo);
-        const int rem = item % (2 * npo);
-        const int which = rem / npo, kk = rem % npo;
-        const int kcol = i + 1 + kk;
-        const T* src = which == 0 ? a.A + (size_t)kcol * a.lda : a.W + (size_t)(kcol - wbase) * a.ldw;
-        const int rbeg = ch * CH;
-        T s = Tr<T>::zero(), eone = Tr<T>::zero();
-        T sv[8], xv[8];
+        const int nitems = 2 * npo * a.nchunk;
+        T scale = Tr<T>::one();
+        bool have_scale = false;
+        for (int item = DMA ? hb : gb * 4 + wave; item < nitems; item += DMA ? a.gh : nitems) {
+            const int ch = item / (2 * npo);
+            const int rem = item % (2 * npo);
+            const int which = rem / npo, kk = rem % npo;
+            const int kcol = i + 1 + kk;
+            const T* src = which == 0 ? a.A + (size_t)kcol * a.lda : a.W + (size_t)(kcol - wbase) * a.ldw;
+            const int rbeg = ch * CH;
+            T s = Tr<T>::zero(), eone = Tr<T>::zero();
+            T sv[8], xv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {   // raw loads, all in flight before the first use
-            int r = rbeg + lane + 64 * j;
-            sv[j] = src[min(r, n - 1)];
-            xv[j] = a.xbuf[min(r, max(nz - 1, 0))];
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < 8; ++j) {   // raw loads, all in flight before the first use
+                int r = rbeg + lane + 64 * j;
+                sv[j] = src[min(r, n - 1)];
+                xv[j] = a.xbuf[min(r, max(nz - 1, 0))];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int r = rbeg + lane + 64 * j;
-            const T sj = sel(r < n, sv[j], zero);
-            fmac_(s, sj, sel(r < nz, xv[j], zero));
-            eone = sel(r == one_at, conj_(sj), eone);
+            for (int j = 0; j < 8; ++j) {
+                int r = rbeg + lane + 64 * j;
+                const T sj = sel(r < n, sv[j], zero);
+                fmac_(s, sj, sel(r < nz, xv[j], zero));
+                eone = sel(r == one_at, conj_(sj), eone);
+            }
+            if (!have_scale) { scale = scalars(); have_scale = true; }
+            s = wave_sum(scale * s + eone);
+            if (lane == 0) a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk] = s;
         }
-        const T scale = scalars();
-        s = wave_sum(scale * s + eone);
-        if (lane == 0) a.Zp[(size_t)(ch * 2 + which) * NBMAX + kk] = s;
+        TSTAMPW(2, 4, T0, 5);   // wave of the stacked products done
+        if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see the end of the kernel
         return;
     }
 
@@ -490,10 +676,10 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         xr_raw = a.xbuf[min(r, max(nz - 1, 0))];
     };
     if (t < ntiles) issue_mine();
-    __syncthreads();
+    if (!DMA) __syncthreads();       // (pairs with the streaming waves' barrier behind their first issue_tile)
     T scale = Tr<T>::one();
     if (!plain) scale = scalars();   // while waves 0-3 multiply the first tile
-    TSTAMP(0, 2, T0);
+    TSTAMPW(0, 2, T0, 4);
     T Sacc = Tr<T>::zero();
     int k = 0;
     while (t < ntiles) {
@@ -506,6 +692,7 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
         t += a.gh;
         if (t < ntiles) issue_mine();
         __syncthreads();   // partial sums of tile k are in redy / redt [k & 1]
+        if (k == 0) TSTAMPW(2, 3, T0, 4);   // finishing wave: first barrier passed
         const int rb = k & 1, xs = k % 3;
         T yv = scale * ((redy[rb][0][lane] + redy[rb][1][lane]) + (redy[rb][2][lane] + redy[rb][3][lane])) + lastc;
         T tv = scale * redt[rb][lane];
@@ -526,7 +713,12 @@ __global__ void __launch_bounds__(MVT, 3) panel_mv_kernel(PanelBatch<T, NB> ab, 
     }
     Sacc = wave_sum(Sacc);
     if (lane == 0) a.S[hb] = Sacc;
-    TSTAMP(0, 5, T0);
+    TSTAMPW(0, 5, T0, 4);
+    // DMA form: this role and the one above may leave loads unconsumed (the up-front norm partials in plain mode / without items).
+    // hipcc merges the pending-load state of every role at the common exit block, which sits in FRONT of the streaming role in
+    // its control-flow graph: the streaming waves then waited for those registers (vmcnt(15), 14, ...) between their DMA
+    // instructions.  An explicit wait the compiler can see (the builtin, not inline asm) empties that state.
+    if (DMA) __builtin_amdgcn_s_waitcnt(0x0F70);
 }
 
 template <class T> __global__ void __launch_bounds__(256) hemv_gather_kernel(int n, int nt, const T* P, int ldp, T* y) {
@@ -811,6 +1003,14 @@ static int hemv_grid(const Ctx& c, int n) {
     return (int)cap;
 }
 
+// Which data path the panel mat-vec of trailing order n takes: option "mv_dma" = the smallest order streamed through the LDS-DMA
+// ring.  The ring's 16-byte pieces are one complex number or a PAIR of rows of a real column, so the real form wants an even
+// leading dimension and 16-byte aligned bases.  Same operations in the same order either way: bit-identical results.
+template <class T> static bool mv_dma_ok(const Ctx& c, int n, int lda, bool aligned) {
+    if (c.mv_dma <= 0 || n < c.mv_dma) return false;
+    return Tr<T>::cx ? true : (aligned && lda % 2 == 0);
+}
+
 template <class T> struct TrdScratch {
     T *xbuf, *P, *S, *Zp, *alphaSlot;
     double* NP;
@@ -854,6 +1054,8 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
         a.xbuf = P.sc.xbuf; a.P = P.sc.P; a.ldp = P.sc.ldp; a.S = P.sc.S; a.Zp = P.sc.Zp; a.NP = P.sc.NP; a.alphaSlot = P.sc.alphaSlot;
     }
     auto set_all = [&](auto f) { for (int q = 0; q < NB; ++q) f(ab.p[q]); };
+    bool dma_aligned = true;    // (real path of the LDS-DMA form: 16-byte pieces = pairs of rows)
+    for (int q = 0; q < nprob && q < NB; ++q) dma_aligned = dma_aligned && ((uintptr_t)pr[q].A % 16 == 0) && ((uintptr_t)pr[q].sc.xbuf % 16 == 0);
     int gh_prev = 0, nchunk_prev = 0;
     for (int i = np - 1; i >= np - nb - 1; --i) {
         const bool last = (i == np - nb - 1);  // finish-only pass for the panel's leftmost column
@@ -874,7 +1076,10 @@ static void latrd_panel(Ctx& c, hipStream_t st, int nprob, const TrdProb<T>* pr,
         int npo = np - 1 - i;
         int gg = (2 * npo * nchunk + 3) / 4;
         set_all([&](PanelArgs<T>& a) { a.nblkA = gA * NPW; a.gh = gh; a.nchunk = nchunk; });
-        hipLaunchKernelGGL((panel_mv_kernel<T, NB>), dim3(gh + gg, nprob), dim3(MVT), 0, st, ab, 0, gg);
+        if (mv_dma_ok<T>(c, n, lda, dma_aligned))
+            hipLaunchKernelGGL((panel_mv_kernel<T, NB, true>), dim3(gh, nprob), dim3(MVD), 0, st, ab, 0, 0);
+        else
+            hipLaunchKernelGGL((panel_mv_kernel<T, NB, false>), dim3(gh + gg, nprob), dim3(MVT), 0, st, ab, 0, gg);
         if (nlaunch) ++*nlaunch;
         if (algo_bytes) *algo_bytes += (double)sizeof(T) * (double)n * (double)(n + 1) * 0.5;
         gh_prev = gh; nchunk_prev = nchunk;
@@ -989,7 +1194,14 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
     a.e = nullptr; a.tau = nullptr; a.xbuf = const_cast<T*>(x); a.P = sc.P; a.ldp = sc.ldp; a.S = sc.S; a.Zp = sc.Zp;
     a.NP = sc.NP; a.alphaSlot = sc.alphaSlot; a.nblkA = 0; a.nchunk = 0;
     a.gh = hemv_grid(c, n);
-    hipLaunchKernelGGL((panel_mv_kernel<T, 1>), dim3(a.gh), dim3(MVT), 0, st, ab, 1, 0);
+    if (mv_dma_ok<T>(c, n, lda, (uintptr_t)A % 16 == 0)) {
+        // (the DMA reads v in 16-byte pieces up to the end of the last tile: from the library's own padded buffer, not the caller's x)
+        EIG_HIP(hipMemcpyAsync(sc.xbuf, x, sizeof(T) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        a.xbuf = sc.xbuf;
+        hipLaunchKernelGGL((panel_mv_kernel<T, 1, true>), dim3(a.gh), dim3(MVD), 0, st, ab, 1, 0);
+    } else {
+        hipLaunchKernelGGL((panel_mv_kernel<T, 1, false>), dim3(a.gh), dim3(MVT), 0, st, ab, 1, 0);
+    }
     if (gather) {
         int nt = (n + HT - 1) / HT;
         hipLaunchKernelGGL((hemv_gather_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, st, n, nt, (const T*)sc.P, sc.ldp, y);

@@ -21,12 +21,13 @@ def run(n, cx=True):
     out1 = (ctypes.c_ulonglong * 36)()
     lib.eigsolve_debug_trd_timing(out1)
     d = [out1[i] - out0[i] for i in range(36)]
-    for k, name in ((0, "mv "), (1, "row")):
+    for k, name in ((0, "mv "), (2, "mv+"), (1, "row")):
         cnt = d[k * 9]
         ph = [d[k * 9 + 1 + p] / max(cnt, 1) for p in range(8)]
         print("n=%5d %s launches=%5d  cumulative cycles at stamps: %s" % (n, name, cnt, " ".join("%7.0f" % x for x in ph)))
 
-for n in (256, 1024, 4096):
+print("EIGSOLVE_MV_DMA =", os.environ.get("EIGSOLVE_MV_DMA"))
+for n in (1024, 1400, 2048, 4096):
     run(n)
 run(1024, cx=False)
 run(2048, cx=False)
