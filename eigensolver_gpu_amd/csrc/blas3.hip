@@ -79,17 +79,17 @@ template <class T> struct GemmArgs {
 //     (i, j), j >  i  ->  tile (i, j - 1)                      rows 0 .. nt/2-1 of the triangle,
 //     (i, j), j <= i  ->  tile (nt-1-i, nt-1-j)                rows nt/2 .. nt-1, point-reflected,
 // both pieces of a super-tile are compact blocks of C.
-template <class T> __device__ __forceinline__ bool tile_of(const GemmArgs<T>& g, int& bx, int& by) {
-    if (g.map == TM_GRID) { bx = blockIdx.x; by = blockIdx.y; return true; }
+template <class G> __device__ __forceinline__ bool tile_of(G& g, unsigned ux, unsigned uy, int& bx, int& by) {   // G: GemmArgs<T>, in any address space
+    if (g.map == TM_GRID) { bx = (int)ux; by = (int)uy; return true; }
     int r, q;
     if (g.map == TM_TRI) {
-        const int t = blockIdx.x;
+        const int t = (int)ux;
         q = (int)((__builtin_sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
         while ((q + 1) * (q + 2) / 2 <= t) ++q;
         while (q * (q + 1) / 2 > t) --q;
         r = t - q * (q + 1) / 2;   // r <= q
     } else {
-        const unsigned u = blockIdx.x;
+        const unsigned u = ux;
         unsigned p = u;
         if (u < (unsigned)g.mfull) p = ((((u >> 9) << 3) + (u & 7u)) << 6) + ((u & 511u) >> 3);
         const unsigned s = p >> 6, j = p & 63u;
@@ -103,6 +103,8 @@ template <class T> __device__ __forceinline__ bool tile_of(const GemmArgs<T>& g,
     if (g.epi.uplo == 1) { bx = r; by = q; } else { bx = q; by = r; }
     return true;
 }
+
+template <class T> __device__ __forceinline__ bool tile_of(const GemmArgs<T>& g, int& bx, int& by) { return tile_of(g, blockIdx.x, blockIdx.y, bx, by); }
 
 // Restrict [kbeg,kend) to where a masked operand tile can be non-zero (skips the zero half of
 // triangular operands: trmm/trsm/hemm-by-two-gemms cost no wasted MFMAs beyond the diagonal tiles).
@@ -145,6 +147,14 @@ template <class T> constexpr int slab_k(bool small) { return Tr<T>::cx ? (small 
 //    80 KB and TWO workgroups share a CU (the padded layout of round 3 put the complex 32x32 forms at 84-98 KB:
 //    one workgroup per CU, MFMA pipe 19-56 % busy on the solve's small products).
 // ------------------------------------------------------------------------------------------------
+// alpha * v (+ beta * c) with the multiply-adds spelled out: the engine has two kernels for the complex 64 x 64 tiles, and left to
+// -ffp-contract the compiler fused `a.x * v.x - a.y * v.y` one way in one of them and the other way in the other (1 ulp apart for
+// a complex alpha: found by the bit-identity check of the two staging paths, profiles/r06_experiments.txt section 2).
+__device__ __forceinline__ double scal_(double al, double v) { return al * v; }
+__device__ __forceinline__ cplx scal_(cplx al, cplx v) {
+    return cplx{fma(al.x, v.x, -(al.y * v.y)), fma(al.x, v.y, al.y * v.x)};
+}
+
 template <class T, int BM, int BN, int TA, int TB, int BK, bool MASKED>
 __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     constexpr bool CX = Tr<T>::cx;
@@ -487,14 +497,324 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
                 if (g.kchunk > 0) {
                     if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * pld] = v;
                 } else {
-                    T out = g.alpha * v;
+                    T out = scal_(g.alpha, v);
                     if (aux && ok) aux[(size_t)gi + (size_t)gj * g.epi.ldaux] = out;
-                    if (use_c) out = out + g.beta * cv[a][b][r];
+                    if (use_c) fma_(out, g.beta, cv[a][b][r]);
                     if (g.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
                     if (ok) g.C[(size_t)gi + (size_t)gj * g.ldc] = out;
                 }
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// gemm_dma_kernel -- the same 64x64 complex tile with its K-slabs staged by LDS-DMA (round 6)
+//
+// global_load_lds_dwordx4 copies 64 x 16 B per wave instruction straight into LDS (lane-linear at the M0 base): no staging
+// registers, no ds_write pass, no select / conjugation arithmetic between the load and the MFMAs.  What makes that possible here:
+//  * 16 B = ONE complex number, so the LDS image is interleaved (re, im) and a fragment read is ONE ds_read_b128 per lane (the
+//    register-staged kernel keeps re / im planes and reads each with ds_read_b64);
+//  * the image is stored in FRAGMENT BLOCKS: block (kb, ib) = the 16 idx x 4 k entries one v_mfma_f64_16x16x4 consumes, 1 KB, in
+//    lane order of the fragment (lane l = idx l & 15, k l >> 4) -- a fragment read is lane-linear, hence conflict-free without any
+//    swizzle, and the block is exactly what one DMA instruction writes.  The SOURCE side is free per lane: an idx-contiguous
+//    operand presents 4 runs of 256 B per instruction, a k-contiguous one 16 runs of 64 B -- the transposition happens in the
+//    addresses, both kinds produce the same image (one code path, the operand kind is a pair of strides);
+//  * masks, zero fill (K remainders, clipped edges) and the unit diagonal of the trapezoid are ADDRESS selects: a lane whose
+//    element is dropped reads a 16-byte zero (or one) constant instead; only the slabs a mask or an edge touches take that path,
+//    the others compute addresses from two strides;
+//  * conjugation is a sign flip of the imaginary part after the fragment read (one v_xor per fragment value).
+// Two LDS stages of 32 KB, two workgroups per CU; slab s+1 is requested right behind the barrier that opens slab s and has the
+// whole slab (>= 4096 MFMA cycles) to land; the only wait is the wave's own vmcnt(0) in front of that barrier.  Same k order and
+// the same lane -> (m, n) mapping as gemm_fast_kernel: results are bit-identical to it.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) double g_dma_zero[2] = {0.0, 0.0};
+__device__ __attribute__((aligned(16))) double g_dma_one[2] = {1.0, 0.0};
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Work item w of a launch = slot (w % (gx * gy)) of the tile map, K-split / batch entry w / (gx * gy): the dimensions the plain
+// kernel gets as its grid.  The kernel is PERSISTENT: gridDim.x workgroups (two per CU) walk the items w = blockIdx.x, + gridDim.x,
+// ... and the slab pipeline runs straight across tile boundaries -- while a tile's last slab is multiplied the first slab of the
+// workgroup's NEXT tile is already on its way into the other LDS stage (the DMA needs no registers, so nothing has to be free for
+// it), and the C read-modify-write of the finished tile overlaps that transfer.  The register-staged kernel pays first-slab
+// latency + epilogue per tile round (7.7 us at two workgroups per CU: 30 % of a K = 64 update).
+struct DmaTile {
+    int ok, w;
+    int i0, j0, z, M, N;
+    int a1, b1, a2, b2, nst1, nst;
+    const cplx *pa, *pb;
+    cplx* pc;
+    int moffA, moffB;
+};
+
+template <bool MASKED>
+__global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int gx, int gy, int gz, int persistent) {
+    using T = cplx;
+    constexpr int BM = 64, BN = 64, BK = BKL, NPL = 2;
+    constexpr int OPB = BK * 64 * 16;     // bytes of one operand's slab: 16 fragment blocks
+    constexpr int STG = 2 * OPB;
+    constexpr int WM = 32, WN = 32, TM = 2, TN = 2;
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slots = gx * gy, total = slots * gz;
+    // Register budget.  The slab loop needs the two operand descriptors and the current tile (~45 SGPRs); the tile map, the batch
+    // strides, alpha / beta / C / the epilogue options are needed only at tile boundaries.  Referenced through `g` they would all be
+    // loaded once and kept alive across the loop -- 106 SGPRs, 175 v_readlane / v_writelane spill moves per slab and 256 VGPRs in
+    // the first version (persistent form 56 TFLOP/s against 63 for the one-tile form).  cold() hands out the kernel-argument block
+    // through a pointer the compiler cannot trace: fields read through it are re-loaded (scalar cache) where they are used.
+    // (The pointer keeps the CONSTANT address space: through a generic pointer every field became a per-lane flat load -- ~40 of
+    //  them in front of a workgroup's first request -- and a K = 64 update ran 38 % slower.)
+    typedef const __attribute__((address_space(4))) GemmArgs<cplx> ColdArgs;
+    auto cold = [&]() -> ColdArgs& {
+        ColdArgs* kp = (ColdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return *kp;
+    };
+    const Operand<T> opA = g.A, opB = g.B;
+    const bool cat = opA.k1 != INT_MAX;
+    const int k1 = cat ? opA.k1 : INT_MAX;
+
+    // the next valid work item at or after w0 (invalid: padding slots of the map, tiles outside the stored triangle / a clipped batch entry)
+    auto decode = [&](int w0) -> DmaTile {
+        DmaTile t;
+        t.ok = 0;
+        ColdArgs& g = cold();     // (shadows the kernel argument on purpose)
+        for (int w = w0; w < total; w += (int)gridDim.x) {
+            // (one item per workgroup: the launch has the plain kernel's 3-D grid and the item is the block index -- the four integer
+            //  divisions below cost a short-K tile 10-30 % of its time, profiles/r06_experiments.txt section 2)
+            const int u = persistent ? w % slots : 0, z = persistent ? w / slots : (int)blockIdx.z;
+            const unsigned ux = persistent ? (unsigned)(u % gx) : blockIdx.x, uy = persistent ? (unsigned)(u / gx) : blockIdx.y;
+            int M = g.M, N = g.N, K = g.K, zs = z;
+            const cplx *pa = g.A.p, *pb = g.B.p;
+            cplx* pc = g.C;
+            int moffA = g.A.moff, moffB = g.B.moff;
+            if (g.bt.count > 0) {
+                const int zb = z / g.bt.splits;
+                zs = z - zb * g.bt.splits;
+                pa += (long)zb * g.bt.sA; pb += (long)zb * g.bt.sB; pc += (long)zb * g.bt.sC;
+                moffA += zb * g.bt.dMoffA; moffB += zb * g.bt.dMoffB;
+                K += zb * g.bt.dK;
+                if (g.bt.capK != INT_MAX) K = min(K, g.bt.capK - zb * g.bt.dcap);
+                M = min(M, g.bt.capM - zb * g.bt.dcap);
+                N = min(N, g.bt.capN - zb * g.bt.dcap);
+            }
+            int tbx, tby;
+            if (!tile_of(g, ux, uy, tbx, tby)) continue;
+            const int i0 = tbx * BM, j0 = tby * BN;
+            if (g.epi.uplo == 1 && i0 > j0 + BN - 1) continue;
+            if (g.epi.uplo == 2 && j0 > i0 + BM - 1) continue;
+            if (i0 >= M || j0 >= N) continue;
+            int kbeg = 0, kend = K;
+            if (g.kchunk > 0) {
+                kbeg = zs * g.kchunk;
+                kend = min(K, kbeg + g.kchunk);
+            }
+            Operand<T> oa = opA, ob = opB;
+            oa.moff = moffA; ob.moff = moffB;
+            trim_k(oa, i0, BM, kbeg, kend);
+            trim_k(ob, j0, BN, kbeg, kend);
+            t.a1 = kbeg; t.b1 = min(kend, k1);
+            t.a2 = cat ? max(kbeg, k1) - k1 : 0; t.b2 = cat ? kend - k1 : 0;
+            t.nst1 = t.b1 > t.a1 ? (t.b1 - t.a1 + BK - 1) / BK : 0;
+            const int nst2 = t.b2 > t.a2 ? (t.b2 - t.a2 + BK - 1) / BK : 0;
+            t.nst = t.nst1 + nst2;
+            // (everything here is wave-uniform; said explicitly so that the two tile descriptors live in SGPRs -- the map's
+            //  square root runs on the vector unit and would drag them into VGPRs: 256 VGPRs + scratch without this)
+            auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+            auto unip = [&](const void* q) -> const void* {
+                const unsigned long long x = (unsigned long long)q;
+                return (const void*)(((unsigned long long)(unsigned)uni((int)(x >> 32)) << 32) | (unsigned)uni((int)(unsigned)x));
+            };
+            t.a1 = uni(t.a1); t.b1 = uni(t.b1); t.a2 = uni(t.a2); t.b2 = uni(t.b2); t.nst1 = uni(t.nst1); t.nst = uni(t.nst);
+            t.ok = 1; t.w = uni(w); t.i0 = uni(i0); t.j0 = uni(j0); t.z = uni(z); t.M = uni(M); t.N = uni(N);
+            t.pa = (const cplx*)unip(pa); t.pb = (const cplx*)unip(pb); t.pc = (cplx*)unip(pc); t.moffA = uni(moffA); t.moffB = uni(moffB);
+            return t;
+        }
+        return t;
+    };
+
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    const int fi = lane & 15, fk = lane >> 4;
+    const unsigned lds0 = lds_offset_of(sm);
+
+    // keep / unit-diagonal predicate of one element, as in gemm_fast_kernel
+    auto pred = [&](const Operand<T>& o, int moff, int sidx, bool ok, int kk, int ke, bool need, bool& one) -> bool {
+        bool keep = ok && kk < ke;
+        one = false;
+        if (MASKED && need) {
+            const int sr = o.trans ? kk : sidx;
+            const int sc = o.trans ? sidx : kk;
+            const int d = sr - sc - moff;
+            const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
+            one = keep && (o.mask == M_UNITTRAP) && (d == 0);
+            keep = keep && km;
+        }
+        return keep;
+    };
+    auto mask_active = [&](const Operand<T>& o, int moff, int x0, int bs, int kl) -> bool {
+        if (!MASKED || o.mask == M_NONE) return false;
+        const int dmin = o.trans ? kl - (x0 + bs - 1) : x0 - (kl + BK - 1);
+        const int dmax = o.trans ? kl + BK - 1 - x0 : x0 + bs - 1 - kl;
+        if (o.mask == M_UPPER) return dmax > 0;
+        if (o.mask == M_SUPPER) return dmax >= 0;
+        if (o.mask == M_LOWER) return dmin < 0;
+        return dmax - moff >= 0;
+    };
+    // wave w requests the fragment blocks (kb = w, ib = 0..3) of both operands: 8 instructions per slab and wave
+    auto request_operand = [&](const Operand<T>& o, int moff, const T* p, long ld, int x0, int xmax, int kl, int ke, unsigned dst) {
+        const long sidx = o.trans ? ld : 1, sk = o.trans ? 1 : ld;
+        const int kk = kl + wave * 4 + fk;                                   // this lane's k inside the segment
+        const bool need = mask_active(o, moff, x0, 64, kl);
+        if (!need && x0 + 64 <= xmax && kl + BK <= ke) {                    // interior slab: two strides
+            const T* src = p + (size_t)(x0 + fi) * sidx + (size_t)kk * sk;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) lds_dma16(src + (size_t)(16 * ib) * sidx, dst + (unsigned)((wave * 4 + ib) * 1024));
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const int sx = x0 + 16 * ib + fi;
+                bool one;
+                const bool keep = pred(o, moff, sx, sx < xmax, kk, ke, need, one);
+                const T* src = p + (size_t)sx * sidx + (size_t)kk * sk;
+                const T* alt = reinterpret_cast<const T*>(one ? g_dma_one : g_dma_zero);
+                lds_dma16(keep ? src : alt, dst + (unsigned)((wave * 4 + ib) * 1024));
+            }
+        }
+    };
+    auto request = [&](const DmaTile& t, int s_, unsigned fs) {          // slab s_ of tile t into LDS stage fs & 1
+        const bool s2 = s_ >= t.nst1;
+        const int kl = s2 ? t.a2 + (s_ - t.nst1) * BK : t.a1 + s_ * BK;
+        const int ke = s2 ? t.b2 : t.b1;
+        const unsigned stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (fs & 1u) * (unsigned)STG));
+        request_operand(opA, t.moffA, s2 ? opA.p2 : t.pa, s2 ? opA.ld2 : opA.ld, t.i0, t.M, kl, ke, stage);
+        request_operand(opB, t.moffB, s2 ? opB.p2 : t.pb, s2 ? opB.ld2 : opB.ld, t.j0, t.N, kl, ke, stage + OPB);
+    };
+
+    const bool use_c = g.kchunk == 0 && !(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0);
+    const double sgnA = opA.conj ? -1.0 : 1.0, sgnB = opB.conj ? -1.0 : 1.0;
+
+    DmaTile cur = decode(persistent ? (int)blockIdx.x : (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+    if (!cur.ok) return;
+    unsigned fs = 0;                       // slabs requested so far (LDS stage = parity)
+    if (cur.nst > 0) { request(cur, 0, fs); wait_vmcnt<0>(); }
+    while (cur.ok) {
+        // (the next tile is decoded twice -- once for the request of its first slab, once when it becomes the current one: two
+        //  descriptors kept alive across the slab loop overflow the 102 SGPRs and spill into VGPR lanes and scratch)
+        d4 acc[NPL][TM][TN];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
+        T cv[TM][TN][4];
+        auto load_c = [&]() {
+            const int ldc_ = cold().ldc;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int gi = cur.i0 + wm0 + a * 16 + (lane & 15);
+                        int gj = cur.j0 + wn0 + b * 16 + (lane >> 4) + 4 * r;
+                        bool ok = gi < cur.M && gj < cur.N;
+                        const T* cp = ok ? cur.pc + (size_t)gi + (size_t)gj * ldc_ : cur.pc;
+                        cv[a][b][r] = *cp;
+                    }
+        };
+        auto mma_slab = [&](unsigned stage_) {
+            const unsigned char* As = sm + (stage_ & 1u) * STG;
+        const unsigned char* Bs = As + OPB;
+#pragma unroll
+        for (int kb = 0; kb < BK / 4; ++kb) {
+            double ar[TM], ai[TM], br[TN], bi[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const d2 v = *reinterpret_cast<const d2*>(As + (kb * 4 + (wm0 >> 4) + a) * 1024 + lane * 16);
+                ar[a] = v.x; ai[a] = sgnA * v.y;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const d2 v = *reinterpret_cast<const d2*>(Bs + (kb * 4 + (wn0 >> 4) + b) * 1024 + lane * 16);
+                br[b] = v.x; bi[b] = sgnB * v.y;
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ar[a], acc[0][a][b], 0, 0, 0);
+                    acc[1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ar[a], acc[1][a][b], 0, 0, 0);
+                }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[0][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(bi[b], ai[a], acc[0][a][b], 0, 0, 1);
+                    acc[1][a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(br[b], ai[a], acc[1][a][b], 0, 0, 0);
+                }
+        }
+        };
+        // all slabs of the tile but the last: request the next one, multiply this one
+        for (int s_ = 0; s_ + 1 < cur.nst; ++s_, ++fs) {
+            __syncthreads();                      // every wave's pieces of this slab have landed (each waited for its own below), and
+                                                  // every wave is done reading the slab before: its stage may be overwritten
+            request(cur, s_ + 1, fs + 1);
+            mma_slab(fs);
+            wait_vmcnt<0>();                      // the slab requested above has landed (this wave's pieces; the barrier covers the rest)
+        }
+        // the last slab (peeled: C of the tile is live only from here on): the next tile's first slab and C fly during its MFMAs
+        if (cur.nst > 0) {
+            __syncthreads();
+            DmaTile nxt;
+            nxt.ok = 0;
+            if (persistent) nxt = decode(cur.w + (int)gridDim.x);
+            if (nxt.ok && nxt.nst > 0) request(nxt, 0, fs + 1);
+            if (use_c) load_c();
+            mma_slab(fs);
+            wait_vmcnt<0>();
+            ++fs;
+        }
+        if (cur.nst == 0) {                       // (empty K range: C <- beta C)
+            if (use_c) load_c();
+            DmaTile nxt;
+            nxt.ok = 0;
+            if (persistent) nxt = decode(cur.w + (int)gridDim.x);
+            if (nxt.ok && nxt.nst > 0) { request(nxt, 0, fs); wait_vmcnt<0>(); }
+        }
+        // epilogue of the finished tile: its stores are in flight while the next tile starts
+        ColdArgs& ge = cold();
+        const T al_ = cplx{ge.alpha.x, ge.alpha.y}, be_ = cplx{ge.beta.x, ge.beta.y};
+        T* const aux = reinterpret_cast<T*>(ge.epi.aux);
+        const int pld = ge.M;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int gi = cur.i0 + wm0 + a * 16 + fi;
+                    int gj = cur.j0 + wn0 + b * 16 + fk + 4 * r;
+                    bool ok = gi < cur.M && gj < cur.N;
+                    if (ge.epi.uplo == 1 && gi > gj) ok = false;
+                    if (ge.epi.uplo == 2 && gi < gj) ok = false;
+                    T v = Tr<T>::make(acc[0][a][b][r], acc[1][a][b][r]);
+                    if (ge.kchunk > 0) {
+                        if (ok) ge.P[(size_t)cur.z * ge.pstride + (size_t)gi + (size_t)gj * pld] = v;
+                    } else {
+                        T out = scal_(al_, v);
+                        if (aux && ok) aux[(size_t)gi + (size_t)gj * ge.epi.ldaux] = out;
+                        if (use_c) fma_(out, be_, cv[a][b][r]);
+                        if (ge.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
+                        if (ok) cur.pc[(size_t)gi + (size_t)gj * ge.ldc] = out;
+                    }
+                }
+            }
+        }
+        if (!persistent) break;
+        cur = decode(cur.w + (int)gridDim.x);
     }
 }
 
@@ -515,9 +835,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
     T s = Tr<T>::zero();
     for (int z = 0; z < splits; ++z) s = s + P[(size_t)z * pstride + id];
     T* cp = C + (size_t)i + (size_t)j * ldc;
-    T out = alpha * s;
+    T out = scal_(alpha, s);
     if (epi.aux) reinterpret_cast<T*>(epi.aux)[(size_t)i + (size_t)j * epi.ldaux] = out;
-    if (!(real_(beta) == 0.0 && imag_(beta) == 0.0)) out = out + beta * (*cp);
+    if (!(real_(beta) == 0.0 && imag_(beta) == 0.0)) fma_(out, beta, *cp);
     if (epi.herm_diag && i == j) out = Tr<T>::realpart(out);
     *cp = out;
 }
@@ -557,7 +877,7 @@ template <class T> static dim3 choose_map(GemmArgs<T>& g, int tm, int tn, bool t
 }
 
 template <class T, int BM, int BN>
-static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map) {
+static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map, int dma = 0) {
     constexpr int BK = slab_k<T>(BM * BN <= 32 * 32);
     GemmArgs<T> g = g_in;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -566,6 +886,19 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, boo
     const dim3 block(256);
     const int ta = g.A.trans, tb = g.B.trans;
     const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
+    if constexpr (Tr<T>::cx && BM == 64 && BN == 64) {
+        if (dma > 0) {     // option "gemm_dma": K-slabs staged by LDS-DMA (the operand kind is a pair of strides there: no TA / TB forms);
+                           // dma = number of workgroups the work items are dealt to: INT_MAX = one item each (option value 1), two
+                           // per CU = the persistent form with the slab pipeline running across tile boundaries (option value 2)
+            const long total = (long)grid.x * grid.y * grid.z;
+            const int pers = total > dma;
+            const dim3 pg = pers ? dim3((unsigned)dma) : grid;
+            if (masked) hipLaunchKernelGGL((gemm_dma_kernel<true>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
+            else hipLaunchKernelGGL((gemm_dma_kernel<false>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
+            EIG_HIP(hipGetLastError());
+            return;
+        }
+    }
 #define EIG_LAUNCH_FAST(TA_, TB_)                                                                                      \
     do {                                                                                                               \
         if (masked) hipLaunchKernelGGL((gemm_fast_kernel<T, BM, BN, TA_, TB_, BK, true>), grid, block, 0, st, g);      \
@@ -585,7 +918,7 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
     // tile is ~256 dependent MFMAs per wave (~15 us), so small problems want many small tiles.
     // (128x128 and 128x64 real tiles were measured in rounds 2-3 and lost inside the solver; they are gone.)
     const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * splits;
-    if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0);
+    if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0, c.gemm_dma == 0 ? 0 : (c.gemm_dma == 2 ? 2 * c.n_cu : INT_MAX));
     else launch_gemm<T, 32, 32>(st, g, splits, c.tile_map != 0);
 }
 

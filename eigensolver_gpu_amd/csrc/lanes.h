@@ -148,6 +148,22 @@ __device__ __forceinline__ int transpose_col_of_lane(int lane) {
     return ((lane >> 2) & 1) + 2 * ((lane >> 4) & 1) + 4 * ((lane >> 5) & 1) + 8 * ((lane >> 3) & 1);
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) -------------------------------------------------------------------------------------
+// One wave instruction copies 64 x 16 B straight from global memory into LDS at [M0 base + 16 * lane]: no VGPR destination, so the
+// number of bytes a wave keeps in flight is bounded by the LDS it owns, not by its registers (MI355X_MICROARCH.md, "LDS-DMA").
+// hipcc does not count these operations (cdna_hip_programming.md 5.7): completion is waited for with explicit s_waitcnt vmcnt(N),
+// and a wave that uses them issues NO other vector-memory loads, so the counts below are exact.  M0 is saved and restored around
+// the instruction (it is compiler-reserved).
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(uintptr_t)p; }   // low half of the flat address
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_wave_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst_wave_uniform)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // 1/x to ~1 ulp without the IEEE division sequence (x normal, nonzero): v_rcp_f64 + two Newton steps
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);

@@ -309,20 +309,7 @@ __device__ __forceinline__ void tile_decode(int t, int& I, int& J) {
     I = t - J * (J + 1) / 2;
 }
 
-// ---- LDS-DMA (global_load_lds_dwordx4) -------------------------------------------------------------------------------------
-// One wave instruction copies 64 x 16 B straight from global memory into LDS at [M0 base + 16 * lane]: no VGPR destination, so the
-// number of bytes a wave keeps in flight is bounded by the LDS it owns, not by its registers (MI355X_MICROARCH.md, "LDS-DMA").
-// hipcc does not count these operations (cdna_hip_programming.md 5.7): completion is waited for with explicit s_waitcnt vmcnt(N),
-// and a wave that uses them issues NO other vector-memory loads, so the counts below are exact.  M0 is saved and restored around
-// the instruction (it is compiler-reserved).
-__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(uintptr_t)p; }   // low half of the flat address
-__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst_wave_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst_wave_uniform)
-                 : "memory");
-}
+// (LDS-DMA primitives: lanes.h)
 // NI instructions of one slot in ONE statement (M0 saved once): instruction q copies [base + voff + q * stride] -> [dst + 1024 q].
 // base, stride, dst wave-uniform; voff = the lane's byte offset.  Three instructions per piece: the M0 update, the offset update
 // (which also is the wait state an M0 write needs in front of an LDS-DMA) and the copy.
@@ -342,7 +329,6 @@ template <int NI> __device__ __forceinline__ void lds_dma16_run(const void* base
                      : "s"(base), "s"(stride), "s"(dst)
                      : "memory");
 }
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Geometry of the LDS ring of panel_mv_kernel<T, NB, true>: every streaming wave owns DEPTH slots; a slot holds the wave's 16
 // columns of one 64 x 64 tile ([column][64 rows], exactly the image the DMA writes: a column of 64 complex numbers is one
