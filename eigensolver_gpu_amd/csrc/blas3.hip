@@ -918,7 +918,13 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
     // tile is ~256 dependent MFMAs per wave (~15 us), so small problems want many small tiles.
     // (128x128 and 128x64 real tiles were measured in rounds 2-3 and lost inside the solver; they are gone.)
     const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * splits;
-    if (tiles64 >= c.n_cu) launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0, c.gemm_dma == 0 ? 0 : (c.gemm_dma == 2 ? 2 * c.n_cu : INT_MAX));
+    if (tiles64 >= c.n_cu) {
+        // staging path (option "gemm_dma"): LDS-DMA pays from ~6 slabs per work item on
+        const int kitem = g.kchunk > 0 ? g.kchunk : g.K + (g.bt.count > 0 && g.bt.dK > 0 ? (g.bt.count - 1) * g.bt.dK : 0);
+        int dma = c.gemm_dma == 0 ? 0 : (c.gemm_dma == 2 ? 2 * c.n_cu : INT_MAX);
+        if (c.gemm_dma == 3 && kitem < kGemmDmaMinK) dma = 0;
+        launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0, dma);
+    }
     else launch_gemm<T, 32, 32>(st, g, splits, c.tile_map != 0);
 }
 

@@ -132,7 +132,11 @@ constexpr int kGstThrDefault = 1024;
 // factorization) or 256 (merged after it, build_inv256 in blas3.hip)
 constexpr int kTrsmBaseDefault = 256;
 inline int norm_trsm_base(int v) { return v >= 1024 ? 1024 : (v >= 512 ? 512 : (v >= 256 ? 256 : 64)); }
-constexpr int kGemmDmaDefault = 0;
+// MFMA engine, complex 64 x 64 tiles: 0 = K-slabs staged through registers (gemm_fast_kernel), 1 = by LDS-DMA (gemm_dma_kernel), 2 = LDS-DMA,
+// persistent form, 3 = LDS-DMA where a work item has at least kGemmDmaMinK of K (measured: +8-9 % at K >= 1024, +4-6 % at 128-256, -0..3 %
+// at K = 64, profiles/r06_experiments.txt section 2); results are bit-identical in every form
+constexpr int kGemmDmaDefault = 3;
+constexpr int kGemmDmaMinK = 96;
 constexpr int kMvDmaDefault = 0;   // (set from the measurements of round 6, profiles/r06_experiments.txt)
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;
@@ -157,7 +161,7 @@ struct Ctx {
     int trd_nb = kTrdNbDefault;
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
-    int gemm_dma = kGemmDmaDefault;   // 1: the complex 64 x 64 tiles of the MFMA engine stage their K-slabs by LDS-DMA (gemm_dma_kernel in blas3.hip)
+    int gemm_dma = kGemmDmaDefault;   // staging path of the complex 64 x 64 tiles (see kGemmDmaDefault)
     int mv_dma = kMvDmaDefault;   // smallest trailing order for which the panel mat-vec streams its tiles through the LDS-DMA ring
                              // (panel_mv_kernel<T, NB, true> in trd.hip); 0 = never (the register-staged form everywhere)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");

@@ -389,7 +389,7 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "trd_finish") { c.trd_finish = value < 0 ? -1 : value; c.drop_graphs(); }
     else if (s == "trace_marks") c.trace_marks = value > 0;
     else if (s == "zs_cap_mb") c.zs_cap_mb = value <= 0 ? kZsCapMbDefault : value;
-    else if (s == "gemm_dma") c.gemm_dma = value < 0 ? kGemmDmaDefault : (value > 2 ? 2 : value);
+    else if (s == "gemm_dma") c.gemm_dma = (value < 0 || value > 3) ? kGemmDmaDefault : value;
     else if (s == "mv_dma") { c.mv_dma = value < 0 ? kMvDmaDefault : value; c.drop_graphs(); }
     else return false;
     return true;

@@ -86,6 +86,12 @@ int eigsolve_set_host_threads(int nthreads);
  *               block -- same results to rounding.  Scope: eigsolve_?hegvdx and the problems a batch call solves one per launch
  *               chain; the LOCKSTEP groups of a batch call (small orders, "batch_fuse" > 1 or "batch_workers" = 0: a matrix of
  *               at most 96 MiB in the automatic setting) and the stage-level eigsolve_?trsm_lun always keep the full block.
+ *   "gemm_dma"  staging path of the MFMA engine's complex 64 x 64 tiles: 0 = global -> registers -> ds_write (gemm_fast_kernel),
+ *               1 = LDS-DMA (global_load_lds_dwordx4 into fragment-ordered LDS blocks, gemm_dma_kernel), 2 = LDS-DMA with persistent
+ *               workgroups, 3 (default) = LDS-DMA for work items with at least 96 of K, registers below.  Same summation order and
+ *               lane mapping in every form: results are bit-identical.
+ *   "mv_dma"    smallest trailing order from which the panel mat-vec streams its tiles through an LDS-DMA ring instead of registers
+ *               (0 = never, the default: measured slower at every order, profiles/r06_experiments.txt section 1); bit-identical results.
  * Returns 0 / -1 (unknown name). */
 int eigsolve_set_option(const char *name, int value);
 

@@ -150,6 +150,108 @@ def test_her2k_vs_numpy(env, cplx, n, k):
         assert np.all(got.diagonal().imag == 0)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("ta,tb,dims", [("N", "N", (1024, 1024, 1024)), ("C", "N", (1024, 512, 777)), ("N", "C", (1000, 1030, 130)),
+                                        ("T", "T", (999, 513, 64)), ("C", "C", (1100, 1100, 17)), ("N", "N", (1027, 515, 1100)),
+                                        ("C", "N", (640, 640, 16)), ("N", "C", (2048, 2048, 96))])
+def test_gemm_staging_paths_vs_numpy(env, ta, tb, dims, mode):
+    """The complex 64 x 64 tiles of the MFMA engine have two data paths (option "gemm_dma": K-slabs through registers and
+    ds_write, or by LDS-DMA into fragment-ordered blocks; one-item, persistent and automatic forms): every form against numpy on
+    grids of >= 256 tiles (smaller products take the 32 x 32 tiles), ragged edges and K remainders included, and bit for bit
+    against the register path."""
+    torch, oracle, api = env
+    M, N, K = dims
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = rnd(rng, True, M, K) if ta == "N" else rnd(rng, True, K, M)
+    B = rnd(rng, True, K, N) if tb == "N" else rnd(rng, True, N, K)
+    C = rnd(rng, True, M, N)
+    f = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    al, be = (0.7 - 0.2j), (0.3 + 0.1j)
+    ref = al * (f[ta](A) @ f[tb](B)) + be * C
+    outs = []
+    try:
+        for md in (0, mode):
+            api.set_option("gemm_dma", md)
+            Cd = api.to_device(C)
+            api.gemm(ta, tb, M, N, K, al, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], be, Cd, M)
+            outs.append(api.to_host(Cd))
+    finally:
+        api.set_option("gemm_dma", -1)
+    assert rel(outs[1], ref) <= 20 * K * EPS
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("n,k", [(2600, 64), (2111, 50), (1999, 17)])
+def test_her2k_staging_paths(env, n, k, mode):
+    """K-concatenated operands (two segments, any boundary), triangular output and the folded tile map on the LDS-DMA path."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n + k)
+    V, W = rnd(rng, True, n, k), rnd(rng, True, n, k)
+    C = rnd(rng, True, n, n)
+    C = C + C.conj().T
+    outs = []
+    try:
+        for md in (0, mode):
+            api.set_option("gemm_dma", md)
+            Cd = api.to_device(C)
+            api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+            outs.append(api.to_host(Cd))
+    finally:
+        api.set_option("gemm_dma", -1)
+    ref = C - V @ W.conj().T - W @ V.conj().T
+    iu = np.triu_indices(n)
+    assert np.abs(outs[1][iu] - ref[iu]).max() <= 50 * k * EPS * np.abs(ref).max()
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n", [65, 777, 1500, 2300])
+def test_hemv_dma_ring_vs_oracle(env, cplx, n):
+    """The panel mat-vec's second data path (option "mv_dma": tiles streamed through an LDS-DMA ring): against the oracle, the
+    lower triangle poisoned, and bit for bit against the register path (same order of every sum)."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n)
+    A = oracle.gen_spd_fast(n, 10 + n, cplx)
+    x = rnd(rng, cplx, n)
+    Au = np.triu(A).copy()
+    Au[np.tril_indices(n, -1)] = np.nan
+    ys = []
+    try:
+        for md in (0, 1):
+            api.set_option("mv_dma", md)
+            ys.append(api.hemv(api.to_device(Au), torch.from_numpy(x).cuda()).cpu().numpy())
+    finally:
+        api.set_option("mv_dma", -1)
+    ref = oracle.herm_from_upper(A) @ x
+    assert rel(ys[1], ref) <= 50 * n * EPS
+    assert np.array_equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_solve_on_either_data_path_is_bit_identical(env, cplx):
+    """Whole generalized solves with both LDS-DMA paths switched on against the register-staged forms: same eigenvalues and
+    eigenvectors bit for bit (the paths differ in how bytes travel, not in the arithmetic)."""
+    torch, oracle, api = env
+    n, m = 1500, 400
+    A = oracle.gen_spd_fast(n, 11, cplx)
+    B = oracle.gen_spd_fast(n, 12, cplx) + n * np.eye(n)
+    res = []
+    try:
+        for gd, md in ((0, 0), (1, 1), (2, 700), (3, 0)):
+            api.set_option("gemm_dma", gd)
+            api.set_option("mv_dma", md)
+            info, ws = api.hegvdx(api.to_device(A), api.to_device(B), 1, m)
+            assert info == 0
+            res.append((ws.w_h.numpy()[:n].copy(), api.to_host(ws.Z_h, n, m)))
+    finally:
+        api.set_option("gemm_dma", -1)
+        api.set_option("mv_dma", -1)
+    assert oracle.residual(A, B, res[0][0], res[0][1]) <= 50 * n * EPS
+    for w, Z in res[1:]:
+        assert np.array_equal(w, res[0][0]) and np.array_equal(Z, res[0][1])
+
+
 # ---------------------------------------------------------------------------------------------
 # stage level vs oracle and vs golden LAPACK fixtures
 # ---------------------------------------------------------------------------------------------
