@@ -584,6 +584,10 @@ def main():
         msk = api.her2k_bench(V, Wm, C, n, nb, reps=10)
         cmul = 4.0 if cplx else 1.0
         fl_her2k = cmul * 2.0 * n * n * nb          # c*2*m^2*k (upper triangle, two products)
+        # the trailing updates AS THE TRIDIAGONALIZATION ISSUES THEM (every order and panel width of one ?hetrd of order N, back to
+        # back): what the solve's her2k launches sustain, beside the one-shape probe above
+        Wp = 1e-3 * torch.randn((64, n), dtype=dt, device=dev)
+        rh = api.hetrd_her2k_sweep(C, Wp, 0, reps=2)
         Bm = torch.randn((n, n), dtype=dt, device=dev)
         Cm = torch.empty((n, n), dtype=dt, device=dev)
         msg = api.gemm_bench("N", "N", n, n, n, A0, n, Bm, n, Cm, n, reps=3)
@@ -594,6 +598,10 @@ def main():
         out["roofline_mfma"] = {
             "bound": "mfma", "peak": MFMA_F64_PEAK_TF, "unit": "TFLOP/s",
             "her2k_k64": {"achieved": fl_her2k / (msk * 1e-3) * 1e-12, "frac": fl_her2k / (msk * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msk},
+            "her2k_in_trd": {"achieved": rh["flops"] / (rh["ms_total"] * 1e-3) * 1e-12, "frac": rh["flops"] / (rh["ms_total"] * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF,
+                             "ms": rh["ms_total"], "launches": rh["launches"],
+                             "note": "every trailing rank-2nb update of one ?hetrd of order N (zhetrd_gpu.F90:67), same orders / panel widths / operand "
+                                     "placement, back to back; flops = sum c*2*n^2*k"},
             "gemm_nn": {"achieved": fl_gemm / (msg * 1e-3) * 1e-12, "frac": fl_gemm / (msg * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF, "ms": msg},
             "blas3_phases_in_solve": {"achieved": (cmul * ((4.0 / 3.0) * n ** 3 + 3.0 * n * n * m)) / (blas3_ms * 1e-3) * 1e-12 if blas3_ms > 0 else None,
                                       "frac": (cmul * ((4.0 / 3.0) * n ** 3 + 3.0 * n * n * m)) / (blas3_ms * 1e-3) * 1e-12 / MFMA_F64_PEAK_TF if blas3_ms > 0 else None,
@@ -606,7 +614,7 @@ def main():
                                               "(default form: hegst beside potrf, T factors beside the tridiagonal solver); per-phase "
                                               "rates and one_stream_frac from the same solve on one stream (isolated_one_stream)"},
         }
-        del V, Wm, C, Bm, Cm, Asw
+        del V, Wm, C, Bm, Cm, Asw, Wp
 
     # ---- CPU baseline (rank 0 only, N=1 only): LAPACK on the host cores, SAME (A,B) as the first GPU problem --------
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -37,7 +37,7 @@ EXPORTS = [
     "eigsolve_zpotrf", "eigsolve_dpotrf", "eigsolve_zhemv", "eigsolve_dsymv", "eigsolve_zhemv_bench",
     "eigsolve_dsymv_bench", "eigsolve_zgemm", "eigsolve_dgemm", "eigsolve_zgemm_bench", "eigsolve_dgemm_bench",
     "eigsolve_zher2k", "eigsolve_dsyr2k", "eigsolve_zher2k_bench", "eigsolve_dsyr2k_bench", "eigsolve_ztrsm_lun",
-    "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep",
+    "eigsolve_dtrsm_lun", "eigsolve_version", "eigsolve_zhetrd_mv_sweep", "eigsolve_dsytrd_mv_sweep", "eigsolve_zhetrd_her2k_sweep", "eigsolve_dsytrd_her2k_sweep",
     "eigsolve_dstedc_device", "eigsolve_zlarft", "eigsolve_dlarft", "eigsolve_zunmtr", "eigsolve_dormtr",
     "eigsolve_zhegvdx_batch", "eigsolve_dsygvdx_batch",
 ]
@@ -407,6 +407,21 @@ def hetrd_mv_sweep(A_d, nb=0, reps=1):
                               ctypes.byref(nl), ctypes.byref(by))
     assert rc == 0
     return {"ms_total": ms.value, "launches": nl.value, "algo_bytes": by.value}
+
+
+def hetrd_her2k_sweep(A_d, W_d, nb=0, reps=1):
+    """Roofline leg: the trailing rank-2nb updates of one full ?hetrd, back to back (W_d: nb x N row-major = N x nb panel workspace).
+    Returns dict(ms_total, launches, flops).  Overwrites A_d."""
+    _sync()
+    N = A_d.shape[0]
+    ms = ctypes.c_double(0)
+    nl = ctypes.c_long(0)
+    fl = ctypes.c_double(0)
+    name = "eigsolve_zhetrd_her2k_sweep" if _pre(A_d) == "z" else "eigsolve_dsytrd_her2k_sweep"
+    rc = getattr(lib(), name)(c_int(N), _p(A_d), c_int(A_d.shape[1]), _p(W_d), c_int(nb), c_int(reps), ctypes.byref(ms),
+                              ctypes.byref(nl), ctypes.byref(fl))
+    assert rc == 0
+    return {"ms_total": ms.value, "launches": nl.value, "flops": fl.value}
 
 
 def bt_block(nb, N):

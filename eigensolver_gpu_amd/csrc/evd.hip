@@ -1151,6 +1151,33 @@ int eigsolve_dsytrd_mv_sweep(int N, double* A_d, int lda, int nb, int reps, doub
     return mv_sweep_entry<double>(N, A_d, lda, nb, reps, ms_total, nlaunch, algo_bytes);
 }
 
+template <class T> static int her2k_sweep_entry(int N, T* A, int lda, T* W, int nb, int reps, double* ms_total, long* nlaunch, double* flops) {
+    return guarded(nullptr, [&]() -> int {
+        Ctx& c = ctx();
+        if (nb <= 0) nb = c.trd_nb;
+        long nl = 0; double fl = 0;
+        hetrd_her2k_sweep<T>(c, c.s1, N, A, lda, W, nb, &nl, &fl);  // warm-up
+        c.sync(c.s1);
+        if (reps < 1) reps = 1;
+        EIG_HIP(hipEventRecord(c.ev[0], c.s1));
+        for (int r = 0; r < reps; ++r) hetrd_her2k_sweep<T>(c, c.s1, N, A, lda, W, nb, &nl, &fl);
+        EIG_HIP(hipEventRecord(c.ev[1], c.s1));
+        c.sync(c.s1);
+        float ms = 0.f;
+        EIG_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        if (ms_total) *ms_total = (double)ms / reps;
+        if (nlaunch) *nlaunch = nl;
+        if (flops) *flops = fl;
+        return 0;
+    });
+}
+int eigsolve_zhetrd_her2k_sweep(int N, void* A_d, int lda, void* W_d, int nb, int reps, double* ms_total, long* nlaunch, double* flops) {
+    return her2k_sweep_entry<cplx>(N, (cplx*)A_d, lda, (cplx*)W_d, nb, reps, ms_total, nlaunch, flops);
+}
+int eigsolve_dsytrd_her2k_sweep(int N, double* A_d, int lda, double* W_d, int nb, int reps, double* ms_total, long* nlaunch, double* flops) {
+    return her2k_sweep_entry<double>(N, A_d, lda, W_d, nb, reps, ms_total, nlaunch, flops);
+}
+
 // ---- stage-level entry points of the back-transformation (zlarft_gpu / zlarfb_gpu, zheevd_gpu.F90:136-213) ----
 template <class T> static int larft_entry(int N, const T* A, int lda, const T* tau, int nb2, T* T_out, int ldt_out) {
     return guarded(nullptr, [&]() -> int {

@@ -22,6 +22,8 @@ template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, in
 // Launches only the panel mat-vec kernels of a full tridiagonalization (bench.py roofline leg).
 template <class T>
 void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, double* e, T* tau, long* nlaunch, double* algo_bytes);
+template <class T>
+void hetrd_her2k_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, long* nlaunch, double* flops);
 
 // Allocates (if needed) every scratch slot hetrd_upper uses for order N and returns one of the pointers
 // (graph capture must not allocate; the pointer doubles as a cache-validity token).

@@ -1171,6 +1171,29 @@ void hetrd_mv_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, 
     if (nbr > 0) panel(np, nbr);
 }
 
+// Roofline leg: the exact sequence of trailing rank-2nb updates of a full tridiagonalization (zhetrd_gpu.F90:67), back to back:
+// same orders, panel widths, operand placement (V = the panel's columns of A, W = the panel workspace) as hetrd_lockstep issues.
+// A and W hold whatever the caller put there.  Returns launches and the model flops c * 2 * n^2 * k per update.
+template <class T>
+void hetrd_her2k_sweep(Ctx& c, hipStream_t st, int N, T* A, int lda, T* W, int nb, long* nlaunch, double* flops) {
+    if (nb <= 0 || nb > NBMAX) nb = NBMAX;
+    const int nx = finish_order<T>(c);
+    const double cm = Tr<T>::cx ? 4.0 : 1.0;
+    *nlaunch = 0; *flops = 0.0;
+    auto trailing = [&](int npn, int nbn) {
+        const int n = npn - nbn;
+        if (n <= 0) return;
+        her2k_un<T>(c, st, n, nbn, A + (size_t)n * lda, lda, W, N, A, lda);
+        *nlaunch += 1;
+        *flops += cm * 2.0 * (double)n * n * nbn;
+    };
+    int np = N;
+    while (np - nb >= nx) { trailing(np, nb); np -= nb; }
+    if (np - nx > 0) trailing(np, np - nx);
+}
+template void hetrd_her2k_sweep<double>(Ctx&, hipStream_t, int, double*, int, double*, int, long*, double*);
+template void hetrd_her2k_sweep<cplx>(Ctx&, hipStream_t, int, cplx*, int, cplx*, int, long*, double*);
+
 template <class T> void hemv_upper(Ctx& c, hipStream_t st, int n, const T* A, int lda, const T* x, T* y, bool gather) {
     if (n <= 0) return;
     TrdScratch<T> sc = trd_scratch<T>(c, n);

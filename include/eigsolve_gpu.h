@@ -218,6 +218,15 @@ int eigsolve_zhetrd_mv_sweep(int N, void *A_d, int lda, int nb, int reps, double
 int eigsolve_dsytrd_mv_sweep(int N, double *A_d, int lda, int nb, int reps, double *ms_total, long *nlaunch,
                              double *algo_bytes);
 
+/* Roofline leg of bench.py: the sequence of trailing rank-2nb updates (zher2k / dsyr2k, zhetrd_gpu.F90:67) that one ?hetrd of
+ * order N issues, back to back on the library stream -- same orders, panel widths and operand placement (V = the panel's columns
+ * of A_d, W_d = an N x nb panel workspace, ld N).  *ms_total = HIP-event time of one sweep (average over reps), *nlaunch = updates
+ * per sweep, *flops = sum of c * 2 * n^2 * k.  A_d is overwritten (each update adds O(|V||W|) to it). */
+int eigsolve_zhetrd_her2k_sweep(int N, void *A_d, int lda, void *W_d, int nb, int reps, double *ms_total, long *nlaunch,
+                                double *flops);
+int eigsolve_dsytrd_her2k_sweep(int N, double *A_d, int lda, double *W_d, int nb, int reps, double *ms_total, long *nlaunch,
+                                double *flops);
+
 /* C = alpha op(A) op(B) + beta C on the fp64 MFMA tile engine (replaces cublas?gemm_v2 call
  * sites).  ta/tb in {'N','T','C'}.  alpha/beta: pointer to 1 (d) or 2 (z)
  * doubles on the host. */

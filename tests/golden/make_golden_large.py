@@ -13,6 +13,8 @@ fixture is a few hundred KB at most.
   c3f_z4096ref.npz same at N=4096 full spectrum
   c5_z2048.npz     C5 problem 0 (zhegvdx N=2048 m=512, both families): w[:512] from LAPACK zhegvx and LAPACK's own
                    residual / backward error / B-orthonormality
+  c2_d2048.npz     C2 (dsygvdx N=2048 m=512), same content, real arithmetic (LAPACK dsygvx / dsygvd)
+  c3_z4096.npz     C3 (zhegvdx N=4096 m=1024), same content (round 6: the reference recipe at the headline configuration)
 """
 import os
 import sys
@@ -57,12 +59,12 @@ def values_only(name, n, seedA, seedB, shift):
     print(name, "ok  %.0f s" % (time.time() - t), flush=True)
 
 
-def c5_case(name, n, m, seedA, seedB):
+def c5_case(name, n, m, seedA, seedB, cplx=True):
     t = time.time()
     out = {}
     for fam, shift in (("wc", float(n)), ("ref", 0.0)):
-        A = oracle.gen_spd_fast(n, seedA, True)
-        B = oracle.gen_spd_fast(n, seedB, True, shift=shift)
+        A = oracle.gen_spd_fast(n, seedA, cplx)
+        B = oracle.gen_spd_fast(n, seedB, cplx, shift=shift)
         w, Z = sl.eigh(A, B, subset_by_index=[0, m - 1], driver="gvx")
         res, berr, bortho = lapack_metrics(A, B, w, Z)
         out["w_" + fam] = w
@@ -83,6 +85,10 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["c5", "c3f", "c4wc", "c4ref"]
     if "c5" in which:
         c5_case("c5_z2048", 2048, 512, 1004, 2004)
+    if "c2" in which:
+        c5_case("c2_d2048", 2048, 512, 1002, 2002, cplx=False)
+    if "c3" in which:
+        c5_case("c3_z4096", 4096, 1024, 1003, 2003)
     if "c3f" in which:
         full_with_vectors("c3f_z4096ref", 4096, 1003, 2003)
     if "c4wc" in which:

@@ -1220,31 +1220,37 @@ def test_c4_full_spectrum_reference_recipe(env, golden_dir, fixture):
 
 
 @pytest.mark.parametrize("fam", ["wc", "ref"])
-def test_c5_zhegvdx_n2048_m512(env, golden_dir, fam):
-    """configs[4], one problem of the batch: zhegvdx N=2048, eigenpairs 1..512, against LAPACK zhegvx (fixture)."""
+@pytest.mark.parametrize("cfg", [("C5", "c5_z2048", True), ("C2", "c2_d2048", False), ("C3", "c3_z4096", True)], ids=lambda c: c[0])
+def test_baseline_config_vs_lapack_fixture(env, golden_dir, cfg, fam):
+    """configs[4] (one problem of the batch: zhegvdx N=2048, eigenpairs 1..512), configs[1] (dsygvdx N=2048, 1..512) and configs[2]
+    (zhegvdx N=4096, 1..1024 -- the headline configuration) on BOTH matrix families -- the shifted one and the reference's own
+    recipe (test_zhegvdx.F90:118-137, cond(B) ~ 1e9-1e10) -- against LAPACK ?hegvx / ?hegvd fixtures of the same seeded input
+    (tests/golden/make_golden_large.py)."""
     torch, oracle, api = env
-    g = np.load(os.path.join(golden_dir, "c5_z2048.npz"))
+    tag, fixture, cplx = cfg
+    g = np.load(os.path.join(golden_dir, fixture + ".npz"))
     n, m = int(g["n"]), int(g["m"])
-    A = oracle.gen_spd_fast(n, int(g["seedA"]), True)
-    B = oracle.gen_spd_fast(n, int(g["seedB"]), True, shift=float(n) if fam == "wc" else 0.0)
+    A = oracle.gen_spd_fast(n, int(g["seedA"]), cplx)
+    B = oracle.gen_spd_fast(n, int(g["seedB"]), cplx, shift=float(n) if fam == "wc" else 0.0)
     info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), 1, m)
     assert info == 0
     w = ws.w_h.numpy()[:n].copy()
     res, berr, bortho = _device_metrics(torch, A, B, ws, n, m)
     l2w = oracle.compare_1d(g["w_" + fam], w[:m])[0]
-    # gate: LAPACK zhegvd (D&C -- the reference's own tridiagonal algorithm and its driver's comparator)
+    # gate: LAPACK ?hegvd (D&C -- the reference's own tridiagonal algorithm and its driver's comparator)
     lap_res, lap_bo = float(g["gvd_residual_" + fam]), float(g["gvd_b_orthonormality_" + fam])
-    _report("C5_zhegvdx_n2048_m512_" + fam, {"residual": res, "N_eps": n * EPS, "b_orthonormality": bortho,
-                                             "backward_error_max": berr, "l2_w_vs_lapack_zhegvx": l2w,
-                                             "lapack_zhegvx": {"residual": float(g["lapack_residual_" + fam]),
-                                                               "b_orthonormality": float(g["lapack_b_orthonormality_" + fam])},
-                                             "lapack_zhegvd_first_m": {"residual": lap_res, "b_orthonormality": lap_bo}})
+    pfx = "zhegv" if cplx else "dsygv"
+    _report("%s_%sdx_n%d_m%d_%s" % (tag, pfx, n, m, fam), {"residual": res, "N_eps": n * EPS, "b_orthonormality": bortho,
+                                                          "backward_error_max": berr, "l2_w_vs_lapack_" + pfx + "x": l2w,
+                                                          "lapack_" + pfx + "x": {"residual": float(g["lapack_residual_" + fam]),
+                                                                                 "b_orthonormality": float(g["lapack_b_orthonormality_" + fam])},
+                                                          "lapack_" + pfx + "d_first_m": {"residual": lap_res, "b_orthonormality": lap_bo}})
     if fam == "wc":
         assert res <= n * EPS and bortho <= 1e-10 and l2w <= 1e-12
-    else:   # reference recipe: judged against LAPACK zhegvx on the same input (SURVEY.md 8(c))
+    else:   # reference recipe: judged against LAPACK on the same input (SURVEY.md 8(c))
         assert res <= max(n * EPS, 4 * lap_res), (res, lap_res)
         assert bortho <= max(1e-10, 10 * lap_bo), (bortho, lap_bo)
-        assert l2w <= 1e-8      # the 512 lowest eigenvalues are insensitive to the factor's rounding
+        assert l2w <= 1e-8      # the lowest quarter of the spectrum is insensitive to the factor's rounding
 
 
 def test_c5_full_size_batch_all_64_problems(env, golden_dir):
