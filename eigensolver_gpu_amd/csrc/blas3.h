@@ -3,6 +3,7 @@
 // inverted diagonal blocks + gemm), potrf, hegst.  Internal header.
 #pragma once
 #include <climits>
+#include <memory>
 
 #include "common.h"
 
@@ -65,6 +66,46 @@ struct GemmBatch {
     int dMoffA = 0, dMoffB = 0, dK = 0;
     int capM = INT_MAX, capN = INT_MAX, capK = INT_MAX, dcap = 0;
 };
+
+// ---- deferred launches: the lockstep groups of a batch call (evd.hip, hegvdx_batch_core) --------------------------------------
+// The problems of a group run the same sequence of launches with different pointers.  While c.rec is set, every launch the
+// BLAS-3 drivers would queue is appended to the recorder instead: products on the MFMA engine as their argument block (kind 1),
+// everything else (small kernels, memsets) as a closure (kind 0).  replay_group() then walks the sequences of the group position
+// by position: a product position becomes ONE launch that carries all problems (pointer table in the kernel arguments,
+// blockIdx.z = problem x K-split: same tiles, same K order per problem as the problem's own launch -> bit-identical results),
+// any other position one launch per problem.  Sequences that do not line up are replayed one problem after the other.
+struct LaunchRec {
+    int kind = 0;
+    std::function<void(hipStream_t)> run;                                          // this launch alone
+    std::function<bool(hipStream_t, const LaunchRec* const*, int)> run_group;       // kind 1: with n - 1 peers as one launch (false: not compatible)
+    std::shared_ptr<const void> gemm_args;                                          // kind 1: the engine's argument block
+    int gemm_type = 0;                                                              // 1 real, 2 complex
+};
+struct GroupRecorder {
+    std::vector<LaunchRec> seq;
+};
+void replay_group(hipStream_t st, GroupRecorder* recs, int n);
+
+// kernel launch / memset that honours the recorder
+template <class... KArgs, class... Args>
+inline void klaunch(Ctx& c, hipStream_t st, void (*kern)(KArgs...), dim3 grid, dim3 block, Args... args) {
+    if (c.rec) {
+        LaunchRec r;
+        r.run = [=](hipStream_t s) { hipLaunchKernelGGL(kern, grid, block, 0, s, static_cast<KArgs>(args)...); };
+        c.rec->seq.push_back(std::move(r));
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, 0, st, static_cast<KArgs>(args)...);
+    }
+}
+inline void kmemset(Ctx& c, hipStream_t st, void* p, int value, size_t bytes) {
+    if (c.rec) {
+        LaunchRec r;
+        r.run = [=](hipStream_t s) { EIG_HIP(hipMemsetAsync(p, value, bytes, s)); };
+        c.rec->seq.push_back(std::move(r));
+    } else {
+        EIG_HIP(hipMemsetAsync(p, value, bytes, st));
+    }
+}
 
 // C(MxN) = alpha * A * B + beta * C.
 template <class T>

@@ -42,6 +42,20 @@ enum TileMapKind {
     TM_TRI = 3,       // 1-D grid over the tiles of the stored triangle, plain enumeration (small / batched grids)
 };
 
+// A lockstep group's launch (replay_group): `count` problems of ONE shape, problem q = blockIdx.z / zper with the pointers of
+// entry q; everything else (extents, masks, strides, K-split, strided-batch descriptor) is shared.
+constexpr int kGroupMax = 4;
+template <class T> struct GemmGroup {
+    int count = 0, zper = 1;
+    const T* Ap[kGroupMax];
+    const T* Ap2[kGroupMax];
+    const T* Bp[kGroupMax];
+    const T* Bp2[kGroupMax];
+    T* Cp[kGroupMax];
+    T* auxp[kGroupMax];
+    T* Pp[kGroupMax];
+};
+
 template <class T> struct GemmArgs {
     int M, N, K;
     T alpha, beta;
@@ -59,6 +73,7 @@ template <class T> struct GemmArgs {
     int mfull;       // slots below this index are dealt in XCD chunks, the rest round-robin
     int mnt;         // TM_FOLD: (even) order of the tile triangle
     GemmBatch bt;    // count > 0: blockIdx.z = batch entry * bt.splits + K-split
+    GemmGroup<T> grp;   // count > 0: blockIdx.z = (problem * zper) + the z index of the problem's own launch
 };
 
 // Tile owned by this workgroup; false = a padding slot of the map (nothing to do).
@@ -181,10 +196,21 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
     // strided batch: entry zb works on operands / output shifted by constant strides, with its own K, mask offsets and
     // (clipped) M, N -- all wave-uniform
     const int pld = g.M;          // leading dimension of the split-K partial blocks
-    int zs = blockIdx.z;
+    int bz = blockIdx.z;          // the z index of the problem's own launch
+    if (g.grp.count > 0) {        // lockstep group: this workgroup's problem
+        // (the pointer table is read through the kernel-argument segment -- g is the first argument --: indexed through the by-value
+        //  copy `g`, which this kernel modifies, the whole argument block moved to scratch memory, 528-560 bytes per lane)
+        typedef const __attribute__((address_space(4))) GemmArgs<T> KArgs;
+        KArgs* kp = (KArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int q = __builtin_amdgcn_readfirstlane(bz / g.grp.zper);
+        bz -= q * g.grp.zper;
+        g.A.p = kp->grp.Ap[q]; g.A.p2 = kp->grp.Ap2[q]; g.B.p = kp->grp.Bp[q]; g.B.p2 = kp->grp.Bp2[q];
+        g.C = kp->grp.Cp[q]; g.epi.aux = kp->grp.auxp[q]; g.P = kp->grp.Pp[q];
+    }
+    int zs = bz;
     if (g.bt.count > 0) {
-        const int zb = blockIdx.z / g.bt.splits;
-        zs = blockIdx.z - zb * g.bt.splits;
+        const int zb = bz / g.bt.splits;
+        zs = bz - zb * g.bt.splits;
         g.A.p += (long)zb * g.bt.sA; g.B.p += (long)zb * g.bt.sB; g.C += (long)zb * g.bt.sC;
         g.A.moff += zb * g.bt.dMoffA; g.B.moff += zb * g.bt.dMoffB;
         g.K += zb * g.bt.dK;
@@ -495,7 +521,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fast_kernel(GemmArgs<T> g) {
                 if (g.epi.uplo == 2 && gi < gj) ok = false;
                 T v = Tr<T>::make(acc[0][a][b][r], CX ? acc[NPL - 1][a][b][r] : 0.0);
                 if (g.kchunk > 0) {
-                    if (ok) g.P[(size_t)blockIdx.z * g.pstride + (size_t)gi + (size_t)gj * pld] = v;
+                    if (ok) g.P[(size_t)bz * g.pstride + (size_t)gi + (size_t)gj * pld] = v;
                 } else {
                     T out = scal_(g.alpha, v);
                     if (aux && ok) aux[(size_t)gi + (size_t)gj * g.epi.ldaux] = out;
@@ -572,7 +598,13 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
         asm volatile("" : "+s"(kp));
         return *kp;
     };
-    const Operand<T> opA = g.A, opB = g.B;
+    Operand<T> opA = g.A, opB = g.B;
+    int gq = 0;                                  // lockstep group (one-item form only): this workgroup's problem
+    if (g.grp.count > 0) {
+        ColdArgs& gc = cold();
+        gq = __builtin_amdgcn_readfirstlane((int)blockIdx.z / gc.grp.zper);
+        opA.p2 = gc.grp.Ap2[gq]; opB.p2 = gc.grp.Bp2[gq];
+    }
     const bool cat = opA.k1 != INT_MAX;
     const int k1 = cat ? opA.k1 : INT_MAX;
 
@@ -586,13 +618,19 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
             //  divisions below cost a short-K tile 10-30 % of its time, profiles/r06_experiments.txt section 2)
             const int u = persistent ? w % slots : 0, z = persistent ? w / slots : (int)blockIdx.z;
             const unsigned ux = persistent ? (unsigned)(u % gx) : blockIdx.x, uy = persistent ? (unsigned)(u / gx) : blockIdx.y;
-            int M = g.M, N = g.N, K = g.K, zs = z;
+            int M = g.M, N = g.N, K = g.K;
             const cplx *pa = g.A.p, *pb = g.B.p;
             cplx* pc = g.C;
+            int zl = z;                              // the z index of the problem's own launch
+            if (g.grp.count > 0) {
+                zl = z - gq * g.grp.zper;
+                pa = g.grp.Ap[gq]; pb = g.grp.Bp[gq]; pc = g.grp.Cp[gq];
+            }
+            int zs = zl;
             int moffA = g.A.moff, moffB = g.B.moff;
             if (g.bt.count > 0) {
-                const int zb = z / g.bt.splits;
-                zs = z - zb * g.bt.splits;
+                const int zb = zl / g.bt.splits;
+                zs = zl - zb * g.bt.splits;
                 pa += (long)zb * g.bt.sA; pb += (long)zb * g.bt.sB; pc += (long)zb * g.bt.sC;
                 moffA += zb * g.bt.dMoffA; moffB += zb * g.bt.dMoffB;
                 K += zb * g.bt.dK;
@@ -628,7 +666,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
                 return (const void*)(((unsigned long long)(unsigned)uni((int)(x >> 32)) << 32) | (unsigned)uni((int)(unsigned)x));
             };
             t.a1 = uni(t.a1); t.b1 = uni(t.b1); t.a2 = uni(t.a2); t.b2 = uni(t.b2); t.nst1 = uni(t.nst1); t.nst = uni(t.nst);
-            t.ok = 1; t.w = uni(w); t.i0 = uni(i0); t.j0 = uni(j0); t.z = uni(z); t.M = uni(M); t.N = uni(N);
+            t.ok = 1; t.w = uni(w); t.i0 = uni(i0); t.j0 = uni(j0); t.z = uni(zl); t.M = uni(M); t.N = uni(N);
             t.pa = (const cplx*)unip(pa); t.pb = (const cplx*)unip(pb); t.pc = (cplx*)unip(pc); t.moffA = uni(moffA); t.moffB = uni(moffB);
             return t;
         }
@@ -787,7 +825,8 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
         // epilogue of the finished tile: its stores are in flight while the next tile starts
         ColdArgs& ge = cold();
         const T al_ = cplx{ge.alpha.x, ge.alpha.y}, be_ = cplx{ge.beta.x, ge.beta.y};
-        T* const aux = reinterpret_cast<T*>(ge.epi.aux);
+        T* const aux = ge.grp.count > 0 ? ge.grp.auxp[gq] : reinterpret_cast<T*>(ge.epi.aux);
+        T* const Pq = ge.grp.count > 0 ? ge.grp.Pp[gq] : ge.P;
         const int pld = ge.M;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -802,7 +841,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
                     if (ge.epi.uplo == 2 && gi < gj) ok = false;
                     T v = Tr<T>::make(acc[0][a][b][r], acc[1][a][b][r]);
                     if (ge.kchunk > 0) {
-                        if (ok) ge.P[(size_t)cur.z * ge.pstride + (size_t)gi + (size_t)gj * pld] = v;
+                        if (ok) Pq[(size_t)cur.z * ge.pstride + (size_t)gi + (size_t)gj * pld] = v;
                     } else {
                         T out = scal_(al_, v);
                         if (aux && ok) aux[(size_t)gi + (size_t)gj * ge.epi.ldaux] = out;
@@ -912,8 +951,88 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, boo
     EIG_HIP(hipGetLastError());
 }
 
+template <class T> static void dispatch_gemm_now(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits, int ngroup);
+
+// one recorded product: its argument block and the z extent of its own launch
+template <class T> struct GemmRec {
+    GemmArgs<T> g;
+    int splits;
+};
+// may b ride in a's launch?  (everything but the pointers must agree)
+template <class T> static bool same_operand_shape(const Operand<T>& a, const Operand<T>& b) {
+    return a.ld == b.ld && a.trans == b.trans && a.conj == b.conj && a.mask == b.mask && a.moff == b.moff && a.ld2 == b.ld2 && a.k1 == b.k1 &&
+           (a.p2 == nullptr) == (b.p2 == nullptr);
+}
+template <class T> static bool same_batch(const GemmBatch& a, const GemmBatch& b) {
+    return a.count == b.count && a.splits == b.splits && a.sA == b.sA && a.sB == b.sB && a.sC == b.sC && a.dMoffA == b.dMoffA &&
+           a.dMoffB == b.dMoffB && a.dK == b.dK && a.capM == b.capM && a.capN == b.capN && a.capK == b.capK && a.dcap == b.dcap;
+}
+template <class T> static bool same_product_shape(const GemmRec<T>& x, const GemmRec<T>& y) {
+    const GemmArgs<T>&a = x.g, &b = y.g;
+    return x.splits == y.splits && a.M == b.M && a.N == b.N && a.K == b.K && real_(a.alpha) == real_(b.alpha) && imag_(a.alpha) == imag_(b.alpha) &&
+           real_(a.beta) == real_(b.beta) && imag_(a.beta) == imag_(b.beta) && same_operand_shape(a.A, b.A) && same_operand_shape(a.B, b.B) &&
+           a.ldc == b.ldc && a.epi.uplo == b.epi.uplo && a.epi.herm_diag == b.epi.herm_diag && a.epi.ldaux == b.epi.ldaux &&
+           (a.epi.aux == nullptr) == (b.epi.aux == nullptr) && a.kchunk == b.kchunk && a.pstride == b.pstride && (a.P == nullptr) == (b.P == nullptr) &&
+           same_batch<T>(a.bt, b.bt);
+}
+
 template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits) {
     if (g.M <= 0 || g.N <= 0) return;
+    if (c.rec) {      // a problem of a lockstep group: the launch is recorded, replay_group() issues it (blas3.h)
+        constexpr int type = Tr<T>::cx ? 2 : 1;
+        auto rec = std::make_shared<GemmRec<T>>(GemmRec<T>{g, splits});
+        Ctx* cp = &c;
+        LaunchRec r;
+        r.kind = 1;
+        r.gemm_type = type;
+        r.gemm_args = rec;
+        r.run = [cp, rec](hipStream_t s) { dispatch_gemm_now<T>(*cp, s, rec->g, rec->splits, 1); };
+        r.run_group = [cp, rec](hipStream_t s, const LaunchRec* const* peers, int n) -> bool {
+            if (n < 2 || n > kGroupMax) return false;
+            GemmArgs<T> g0 = rec->g;
+            g0.grp.count = n; g0.grp.zper = rec->splits;
+            for (int q = 0; q < n; ++q) {
+                if (peers[q]->kind != 1 || peers[q]->gemm_type != type) return false;
+                const GemmRec<T>& pq = *static_cast<const GemmRec<T>*>(peers[q]->gemm_args.get());
+                if (!same_product_shape(*rec, pq)) return false;
+                g0.grp.Ap[q] = pq.g.A.p; g0.grp.Ap2[q] = pq.g.A.p2; g0.grp.Bp[q] = pq.g.B.p; g0.grp.Bp2[q] = pq.g.B.p2;
+                g0.grp.Cp[q] = pq.g.C; g0.grp.auxp[q] = reinterpret_cast<T*>(pq.g.epi.aux); g0.grp.Pp[q] = pq.g.P;
+            }
+            dispatch_gemm_now<T>(*cp, s, g0, rec->splits, n);
+            return true;
+        };
+        c.rec->seq.push_back(std::move(r));
+        return;
+    }
+    dispatch_gemm_now<T>(c, st, g, splits, 1);
+}
+
+void replay_group(hipStream_t st, GroupRecorder* recs, int n) {
+    bool aligned = n >= 2;
+    for (int q = 1; q < n && aligned; ++q) {
+        aligned = recs[q].seq.size() == recs[0].seq.size();
+        for (size_t i = 0; aligned && i < recs[0].seq.size(); ++i) aligned = recs[q].seq[i].kind == recs[0].seq[i].kind;
+    }
+    if (!aligned) {
+        for (int q = 0; q < n; ++q)
+            for (LaunchRec& r : recs[q].seq) r.run(st);
+        return;
+    }
+    const LaunchRec* peers[kGroupMax];
+    for (size_t i = 0; i < recs[0].seq.size(); ++i) {
+        bool merged = false;
+        if (recs[0].seq[i].kind == 1 && n <= kGroupMax) {
+            for (int q = 0; q < n; ++q) peers[q] = &recs[q].seq[i];
+            merged = recs[0].seq[i].run_group(st, peers, n);
+        }
+        if (!merged)
+            for (int q = 0; q < n; ++q) recs[q].seq[i].run(st);
+    }
+    EIG_HIP(hipGetLastError());
+}
+
+// ngroup > 1: g carries a lockstep group (g.grp): ngroup times the z extent, the tile shape and data path of ONE problem's launch
+template <class T> static void dispatch_gemm_now(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits, int ngroup) {
     // pick the largest tile that still yields about one workgroup per CU: a 64x64x64 complex
     // tile is ~256 dependent MFMAs per wave (~15 us), so small problems want many small tiles.
     // (128x128 and 128x64 real tiles were measured in rounds 2-3 and lost inside the solver; they are gone.)
@@ -921,11 +1040,11 @@ template <class T> static void dispatch_gemm(Ctx& c, hipStream_t st, const GemmA
     if (tiles64 >= c.n_cu) {
         // staging path (option "gemm_dma"): LDS-DMA pays from ~6 slabs per work item on
         const int kitem = g.kchunk > 0 ? g.kchunk : g.K + (g.bt.count > 0 && g.bt.dK > 0 ? (g.bt.count - 1) * g.bt.dK : 0);
-        int dma = c.gemm_dma == 0 ? 0 : (c.gemm_dma == 2 ? 2 * c.n_cu : INT_MAX);
+        int dma = c.gemm_dma == 0 ? 0 : ((c.gemm_dma == 2 && ngroup == 1) ? 2 * c.n_cu : INT_MAX);
         if (c.gemm_dma == 3 && kitem < kGemmDmaMinK) dma = 0;
-        launch_gemm<T, 64, 64>(st, g, splits, c.tile_map != 0, dma);
+        launch_gemm<T, 64, 64>(st, g, splits * ngroup, c.tile_map != 0, dma);
     }
-    else launch_gemm<T, 32, 32>(st, g, splits, c.tile_map != 0);
+    else launch_gemm<T, 32, 32>(st, g, splits * ngroup, c.tile_map != 0);
 }
 
 template <class T>
@@ -965,8 +1084,8 @@ void gemm(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Operand<T>
                     g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits);
                     dispatch_gemm(c, st, g, splits);
                     size_t total = (size_t)M * N;
-                    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N,
-                                       splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
+                    klaunch(c, st, (splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), M, N,
+                            splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
                     EIG_HIP(hipGetLastError());
                     return;
                 }
@@ -993,8 +1112,8 @@ void gemm_splitk(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Ope
     g.P = c.scratch<T>(splitk_slot(c, st), g.pstride * splits);
     dispatch_gemm(c, st, g, splits);
     size_t total = (size_t)M * N;
-    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, splits,
-                       (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
+    klaunch(c, st, (splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), M, N, splits,
+            (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, GemmBatch());
     EIG_HIP(hipGetLastError());
 }
 
@@ -1022,8 +1141,8 @@ void gemm_batched(Ctx& c, hipStream_t st, int M, int N, int K, T alpha, const Op
     dispatch_gemm(c, st, g, splits * bt.count);
     if (splits > 1) {
         size_t total = (size_t)M * N;
-        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256), bt.count), dim3(256), 0, st, M, N,
-                           splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, bt);
+        klaunch(c, st, (splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256), bt.count), dim3(256), M, N,
+                splits, (const T*)g.P, g.pstride, alpha, beta, C, ldc, epi, bt);
         EIG_HIP(hipGetLastError());
     }
 }
@@ -1798,15 +1917,15 @@ template <class T> static void build_inv256_groups(Ctx& c, hipStream_t st, int N
     if (ng <= 0) return;
     const T* inv64 = c.scratch<T>("invU", 0);
     T* inv256 = c.scratch<T>("invU256", (size_t)ngall * BB * BB);
-    EIG_HIP(hipMemsetAsync(inv256 + (size_t)g0 * BB * BB, 0, sizeof(T) * (size_t)ng * BB * BB, st));
-    hipLaunchKernelGGL((place_inv64_kernel<T>), dim3(ng * 4), dim3(256), 0, st, nblk64, inv64, inv256, g0);
+    kmemset(c, st, inv256 + (size_t)g0 * BB * BB, 0, sizeof(T) * (size_t)ng * BB * BB);
+    klaunch(c, st, (place_inv64_kernel<T>), dim3(ng * 4), dim3(256), nblk64, inv64, inv256, g0);
     EIG_HIP(hipGetLastError());
     T* X = c.scratch<T>("inv_X", (size_t)ngall * 128 * 128);
     T* G0 = inv256 + (size_t)g0 * BB * BB;
     const size_t k00 = (size_t)g0 * BB;
     auto merge = [&](int s_, int r0) {
         const int c0 = r0 + s_;
-        EIG_HIP(hipMemsetAsync(X, 0, sizeof(T) * (size_t)ng * s_ * s_, st));     // rows clipped at the matrix end stay zero
+        kmemset(c, st, X, 0, sizeof(T) * (size_t)ng * s_ * s_);     // rows clipped at the matrix end stay zero
         GemmBatch b1;                                                              // X = M R
         b1.count = ng; b1.sA = (long)BB * (ldu + 1); b1.sB = (long)BB * BB; b1.sC = (long)s_ * s_; b1.dcap = BB;
         b1.capM = N - (int)k00 - r0; b1.capK = N - (int)k00 - c0;
@@ -1871,8 +1990,8 @@ template <class T> static void build_inv_level(Ctx& c, hipStream_t st, int N, co
     const int sub = big / 2, ng = (N + big - 1) / big;
     const T* src = sub == BB ? c.scratch<T>("invU256", 0) : c.scratch<T>(big_slot(sub), 0);
     T* dst = c.scratch<T>(big_slot(big), (size_t)ng * big * big);
-    EIG_HIP(hipMemsetAsync(dst, 0, sizeof(T) * (size_t)ng * big * big, st));
-    hipLaunchKernelGGL((place_inv_kernel<T>), dim3(64, ng * 2), dim3(256), 0, st, N, sub, big, src, dst);
+    kmemset(c, st, dst, 0, sizeof(T) * (size_t)ng * big * big);
+    klaunch(c, st, (place_inv_kernel<T>), dim3(64, ng * 2), dim3(256), N, sub, big, src, dst);
     T* tmp = c.scratch<T>("inv_tmp", (size_t)sub * sub);
     for (int g = 0; g < ng; ++g) {
         const int k = g * big;
@@ -2084,7 +2203,7 @@ template <class T> static void build_invU_range(Ctx& c, hipStream_t st, int N, c
     const int nblk = (N + DB - 1) / DB;
     if (nb <= 0) return;
     T* invU = c.scratch<T>("invU", (size_t)nblk * DB * DB);
-    hipLaunchKernelGGL((diag_block_kernel<T>), dim3(nb), dim3(DGT), 0, st, N, const_cast<T*>(U), ldu, invU, 0, -1, c.d_info, blk0);
+    klaunch(c, st, (diag_block_kernel<T>), dim3(nb), dim3(DGT), N, const_cast<T*>(U), ldu, invU, 0, -1, c.d_info, blk0);
     EIG_HIP(hipGetLastError());
 }
 
@@ -2167,11 +2286,11 @@ template <class T> static void hegst_two_solves_at(Ctx& c, hipStream_t st, int N
     T* F = c.scratch<T>(Tr<T>::cx ? "gst_Fz" : "gst_Fd", (size_t)N * N);
     T* G = c.scratch<T>(Tr<T>::cx ? "gst_Gz" : "gst_Gd", (size_t)N * N);
     const int nb32 = (N + 31) / 32;
-    hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, N, (const T*)Ablk, lda, F, N);
+    klaunch(c, st, (herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), N, (const T*)Ablk, lda, F, N);
     trsm_LUC(c, st, N, N, U, ldu, k0, F, N, G, N, c.trsm_base);   // G = U(k0.., k0..)^-H F
     trsm_RUN(c, st, N, N, U, ldu, k0, G, N, F, N, c.trsm_base);   // F = G U(k0.., k0..)^-1
     size_t tot = (size_t)N * N;
-    hipLaunchKernelGGL((copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, (const T*)F, N, Ablk, lda);
+    klaunch(c, st, (copy_upper_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), N, (const T*)F, N, Ablk, lda);
     EIG_HIP(hipGetLastError());
 }
 template <class T> void hegst_two_solves(Ctx& c, hipStream_t st, int N, T* A, int lda, const T* U, int ldu) {
@@ -2201,7 +2320,7 @@ static void hegst_block_step(Ctx& c, hipStream_t st, int n1, int n2, int k0, T* 
     trsm_LUC(c, st, n1, n2, U, ldu, k0, A12, lda, Tm, n1, base);      // T = U11^-H A12
     {
         const int nb32 = (n1 + 31) / 32;                               // Herm(A11) completed once: the product is a plain full-rate gemm
-        hipLaunchKernelGGL((herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), 0, st, n1, (const T*)A11, lda, H, n1);
+        klaunch(c, st, (herm_complete_kernel<T>), dim3(nb32, nb32), dim3(256), n1, (const T*)A11, lda, H, n1);
     }
     {
         Epi e; e.aux = Xh; e.ldaux = n1;                               // T -= 1/2 Herm(A11) U12,  Xh = -1/2 Herm(A11) U12
@@ -2216,7 +2335,7 @@ static void hegst_block_step(Ctx& c, hipStream_t st, int n1, int n2, int k0, T* 
     }
     {
         const size_t tot = (size_t)n1 * n2;                            // T += Xh
-        hipLaunchKernelGGL((add_block_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n1, n2, (const T*)Xh, n1, Tm, n1);
+        klaunch(c, st, (add_block_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), n1, n2, (const T*)Xh, n1, Tm, n1);
     }
     if (gate) gate->need(k0 + n1 + n2);                                // U22 from here on
     trsm_RUN(c, st, n2, n1, U, ldu, k0 + n1, Tm, n1, A12, lda, base); // A12 = T U22^-1
@@ -2228,8 +2347,8 @@ template <class T> static void hegst_rec(Ctx& c, hipStream_t st, int n, int k0, 
     if (n <= 0) return;
     const T* invU = c.scratch<T>("invU", 0);
     if (n <= DB) {
-        hipLaunchKernelGGL((hegs2_block_kernel<T>), dim3(1), dim3(256), 0, st, n, A + (size_t)k0 + (size_t)k0 * lda, lda,
-                           invU + (size_t)(k0 / DB) * DB * DB);
+        klaunch(c, st, (hegs2_block_kernel<T>), dim3(1), dim3(256), n, A + (size_t)k0 + (size_t)k0 * lda, lda,
+                invU + (size_t)(k0 / DB) * DB * DB);
         EIG_HIP(hipGetLastError());
         return;
     }

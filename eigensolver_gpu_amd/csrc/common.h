@@ -141,6 +141,8 @@ constexpr int kMvDmaDefault = 0;   // (set from the measurements of round 6, pro
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;
 
+struct GroupRecorder;   // blas3.h
+
 struct Ctx {
     int dev = -1;
     hipStream_t s1 = nullptr;  // compute stream: LEASED from the library's stream pool for the duration of an API call
@@ -152,6 +154,14 @@ struct Ctx {
     hipEvent_t evA = nullptr, evB = nullptr;
     hipEvent_t evStage[16] = {};   // block-row stages of the factorization (potrf || hegst pipeline), created on first use
     std::map<std::string, std::pair<void*, size_t>> slots;  // named grow-only device scratch
+    // Lockstep groups of a batch call (hegvdx_batch_core in evd.hip): while `rec` is set the BLAS-3 drivers append their launches to it
+    // instead of queueing them (blas3.h: GroupRecorder), and while grp_q > 0 every scratch slot name gets the suffix "#g<grp_q>" --
+    // each problem of a group works in slots of its own, so the recorded sequences of the group can be replayed position by
+    // position (one launch carrying all problems where the position is a product on the MFMA engine).  slot_gen counts slot
+    // (re)allocations: a recording during which it moved holds stale pointers and is repeated.
+    GroupRecorder* rec = nullptr;
+    int grp_q = 0;
+    unsigned long slot_gen = 0;
     std::map<std::string, std::pair<void*, size_t>> hslots; // named grow-only pinned host scratch
     int* d_info = nullptr;   // device int (replaces devInfo_d)
     int* h_info = nullptr;   // pinned host mirror
@@ -189,6 +199,8 @@ struct Ctx {
                              // (hetd2_wide_kernel in trd.hip): -1 = the largest order its LDS holds, 32 = the reference's cut-over
                              // (zhetrd_gpu.F90:84-87)
     int tile_map = 1;        // 1: XCD-aware super-tile map of the MFMA engine's workgroups (tile_of in blas3.hip), 0: plain grids
+    int batch_zip = 3;       // lockstep groups: the BLAS-3 phases of a group as zipped launch sequences (one launch per product position for the
+                             // whole group; hegvdx_batch_core in evd.hip), 0 = problem after problem (round 3-5 form)
     int batch_fuse = -1;     // problems per launch chain of a batch call that share the per-column launches of the tridiagonalization
                              // (lockstep groups of <= 4): -1 = automatic (groups while a matrix is <= 96 MiB), 1 = none
     int batch_workers = -1;  // problems in flight inside one eigsolve_?hegvdx_batch call (internal worker threads, one context +

@@ -102,9 +102,13 @@ void try_roctx() {
 }  // namespace
 
 // may_fail: "not enough device memory" is an answer (nullptr; the slot is then empty, nothing is printed), not an exception
-static void* scratch_grow(Ctx& c, const char* name, size_t bytes, bool may_fail) {
+static void* scratch_grow(Ctx& c, const char* name0, size_t bytes, bool may_fail) {
+    char nbuf[64];
+    const char* name = name0;
+    if (c.grp_q > 0) { snprintf(nbuf, sizeof nbuf, "%s#g%d", name0, c.grp_q); name = nbuf; }   // (a group's problems: slots of their own)
     auto& s = c.slots[name];
     if (s.second < bytes) {
+        ++c.slot_gen;
         if (s.first) {
             if (c.lease_depth > 0) c.sync(c.s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
             if (c.s2) EIG_HIP(hipStreamSynchronize(c.s2));
@@ -225,7 +229,7 @@ void copy_options(Ctx& c, const Ctx& d) {
     c.trd_nb = d.trd_nb; c.bt_nb = d.bt_nb; c.hemv_blocks = d.hemv_blocks; c.use_graph = d.use_graph; c.overlap = d.overlap;
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.real_il_reference = d.real_il_reference; c.tile_map = d.tile_map;
-    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.batch_fuse = d.batch_fuse; c.trd_finish = d.trd_finish;
+    c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.batch_fuse = d.batch_fuse; c.batch_zip = d.batch_zip; c.trd_finish = d.trd_finish;
     c.zs_cap_mb = d.zs_cap_mb; c.mv_dma = d.mv_dma; c.gemm_dma = d.gemm_dma;
 }
 
@@ -369,7 +373,7 @@ void stream_pool_finalize(int dev) {
 // One table: eigsolve_set_option(name, value) and the environment variable EIGSOLVE_<NAME> (read when a context is created;
 // same value semantics, plus the words "host" / "device" for TRIDIAG and "rec" for POTRF) go through apply_option.
 static const char* const kOptionNames[] = {"trd_nb", "bt_nb", "hemv_blocks", "real_il_reference", "graph", "overlap", "trsm_base",
-                                           "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "tridiag", "tile_map",
+                                           "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "batch_zip", "tridiag", "tile_map",
                                            "trd_finish", "trace_marks", "zs_cap_mb", "mv_dma", "gemm_dma"};
 bool apply_option(Ctx& c, const std::string& s, int value) {
     if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? kTrdNbDefault : value; c.drop_graphs(); }
@@ -384,6 +388,7 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "gst_thr") c.gst_thr = value <= 0 ? kGstThrDefault : (value < 256 ? 256 : value);
     else if (s == "batch_workers") c.batch_workers = (value < 0 || value > 16) ? -1 : value;
     else if (s == "batch_fuse") c.batch_fuse = (value < 1 || value > 4) ? -1 : value;
+    else if (s == "batch_zip") c.batch_zip = (value < 0 || value > 3) ? 3 : value;
     else if (s == "tridiag") c.tridiag_device = value < 0 ? kTridiagDefault : (value > 0 ? 1 : 0);
     else if (s == "tile_map") c.tile_map = value != 0;
     else if (s == "trd_finish") { c.trd_finish = value < 0 ? -1 : value; c.drop_graphs(); }

@@ -168,7 +168,7 @@ static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const
     const int nblk = (k + nb2 - 1) / nb2;
     const int ldt = nb2;
     T* Tall = c.scratch<T>("bt_T", (size_t)nblk * ldt * ldt);
-    EIG_HIP(hipMemsetAsync(Tall, 0, sizeof(T) * (size_t)nblk * ldt * ldt, st));
+    kmemset(c, st, Tall, 0, sizeof(T) * (size_t)nblk * ldt * ldt);
     {
         const T* V = A + (size_t)lda;                 // block b: V + b*nb2*lda, rows 0..mi-1, mi = min((b+1) nb2, k)
         Operand<T> Va = op_plain(V, lda, 1, 1);       // (r,p) -> conj(V(p,r))
@@ -183,8 +183,8 @@ static void bt_build_T(Ctx& c, hipStream_t st, int N, const T* A, int lda, const
         gemm_batched<T>(c, st, ib0, ib0, ib0, Tr<T>::one(), Va, Vb, Tr<T>::zero(), Tall, ldt, e, bt, 512);
     }
     const int parts = nb2 / 64;
-    hipLaunchKernelGGL((finish_T_kernel<T>), dim3(nblk * parts), dim3(64), 0, st, k, nb2, Tall, ldt, tau);
-    if (nb2 >= 128) hipLaunchKernelGGL((merge_T_kernel<T>), dim3(nblk * (nb2 / 128)), dim3(256), 0, st, k, nb2, Tall, ldt);
+    klaunch(c, st, (finish_T_kernel<T>), dim3(nblk * parts), dim3(64), k, nb2, Tall, ldt, tau);
+    if (nb2 >= 128) klaunch(c, st, (merge_T_kernel<T>), dim3(nblk * (nb2 / 128)), dim3(256), k, nb2, Tall, ldt);
     EIG_HIP(hipGetLastError());
     for (int s_ = 128; 2 * s_ <= nb2; s_ *= 2) {      // merge pairs of s_-blocks; everything beyond the last reflector is zero
         T* X = c.scratch<T>("bt_X", (size_t)nblk * s_ * s_);
@@ -570,21 +570,43 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
     const int m = iu - il + 1;
     if (!Tr<T>::cx && c.real_il_reference) { iu = iu - il + 1; il = 1; }   // as heevd_core (dsyevd_gpu.F90:108)
     int* h_inf = reinterpret_cast<int*>(c.host_scratch_bytes("batch_info", sizeof(int) * (size_t)nprob));
+    // The BLAS-3 phases of a group: every problem's launches are RECORDED (blas3.h: GroupRecorder; problem j of the group works in
+    // scratch slots "<name>#g<j>"), then replayed position by position -- a product on the MFMA engine as one launch for the whole
+    // group, anything else once per problem.  A recording during which a slot was (re)allocated holds stale pointers: repeated.
+    struct RecGuard { Ctx& c; ~RecGuard() { c.rec = nullptr; c.grp_q = 0; } } rec_guard{c};
+    auto grouped = [&](int nq, const std::function<void(int)>& body) {      // body(j): the launches of problem j of the group
+        GroupRecorder recs[4];
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            const unsigned long gen = c.slot_gen;
+            for (int j = 0; j < nq; ++j) {
+                recs[j].seq.clear();
+                c.rec = &recs[j]; c.grp_q = j;
+                body(j);
+            }
+            c.rec = nullptr; c.grp_q = 0;
+            if (c.slot_gen == gen) break;
+        }
+        replay_group(st, recs, nq);
+    };
+    const bool zipA = (c.batch_zip & 1) != 0, zipC = (c.batch_zip & 2) != 0;
     {
         PhaseRange r("batch: potrf + hegst");
         if (c.potrf_mode != 0 && nprob > 1) {
-            // the block-row chains of the group in lockstep (64 x 42 us of latency per factorization, shared), then per problem:
-            // its inverse diagonal blocks (one set of scratch slots per context) and its reduction to standard form
+            // the block-row chains of the group in lockstep (64 x 42 us of latency per factorization, shared), then its inverse
+            // diagonal blocks and its reduction to standard form
             for (int q0 = 0; q0 < nprob; q0 += 4) {
                 const int nq = std::min(4, nprob - q0);
                 potrf_upper_group<T>(c, st, N, nq, B + q0, ldb);
                 for (int q = q0; q < q0 + nq; ++q)
                     EIG_HIP(hipMemcpyAsync(&h_inf[q], c.d_info + 4 + (q - q0), sizeof(int), hipMemcpyDeviceToHost, st));
-                for (int q = q0; q < q0 + nq; ++q) {
+                auto body = [&](int j) {
+                    const int q = q0 + j;
                     build_invU<T>(c, st, N, (const T*)B[q], ldb);
                     build_inv_blocks<T>(c, st, N, (const T*)B[q], ldb);
                     hegst_upper<T>(c, st, N, A[q], lda, B[q], ldb);   // (meaningless if B[q] was not positive definite: checked below)
-                }
+                };
+                if (zipA) grouped(nq, body);
+                else for (int j = 0; j < nq; ++j) body(j);
             }
         } else {
             for (int q = 0; q < nprob; ++q) {
@@ -608,24 +630,12 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
             bad = 1;
         }
     }
-    for (int q = 0; q < nprob; ++q) {
-        if (infos[q] != 0) continue;
-        double* Qd = nullptr;
-        int ldq_d = 0;
-        {
-            PhaseRange r(Tr<T>::cx ? "zstedc" : "dstedc");
-            if (stedc_device(c, st, N, w_d[q], e_d[q], w_d[q], &Qd, &ldq_d, il, iu) != 0) {
-                printf(" eigsolve error: device tridiagonal eigensolver failed! (batch problem %d)\n", q);
-                infos[q] = -1;
-                bad = 1;
-                continue;
-            }
-        }
-        size_t tot = (size_t)N * m;
+    const size_t tot = (size_t)N * m;
+    // everything behind the tridiagonal eigensolver for problem q, its eigenvectors of T in Qd
+    auto tail = [&](int q, const double* Qd, int ldq_d) {
         T* Zs = c.scratch<T>(Tr<T>::cx ? "evd_Zsz" : "evd_Zsd", (size_t)N * m);   // as in hegvdx_core
-        hipLaunchKernelGGL((widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, m,
-                           (const double*)(Qd + (size_t)(il - 1) * ldq_d), ldq_d, Zs, N);
-        EIG_HIP(hipMemcpyAsync(w_h[q], w_d[q], sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        klaunch(c, st, (widen_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), N, m, (const double*)(Qd + (size_t)(il - 1) * ldq_d),
+                ldq_d, Zs, N);
         {
             PhaseRange r(Tr<T>::cx ? "zunmtr" : "dormtr");
             bt_build_T<T>(c, st, N, A[q], lda, tau_d[q], c.bt_nb);
@@ -635,13 +645,56 @@ static int hegvdx_batch_core(Ctx& c, int nprob, int N, T* const* A, int lda, T* 
         build_invU<T>(c, st, N, (const T*)B[q], ldb);
         build_inv_blocks<T>(c, st, N, (const T*)B[q], ldb);
         trsm_LUN<T>(c, st, N, m, B[q], ldb, 0, Zs, N, Z[q], ldz, c.trsm_base);
-        if (!skip_host_copy) {
-            hipError_t e = hipMemcpy2DAsync(Z_h[q], sizeof(T) * ldz_h, Z[q], sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
-            if (e != hipSuccess) {
-                printf(" %s error: hipMemcpy2D failed!\n", name);
-                infos[q] = -1;
-                bad = 1;
+    };
+    auto host_copy = [&](int q) {
+        if (skip_host_copy) return;
+        hipError_t e = hipMemcpy2DAsync(Z_h[q], sizeof(T) * ldz_h, Z[q], sizeof(T) * ldz, sizeof(T) * N, m, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            printf(" %s error: hipMemcpy2D failed!\n", name);
+            infos[q] = -1;
+            bad = 1;
+        }
+    };
+    auto tridiag = [&](int q, double** Qd, int* ldq_d) -> bool {
+        PhaseRange r(Tr<T>::cx ? "zstedc" : "dstedc");
+        if (stedc_device(c, st, N, w_d[q], e_d[q], w_d[q], Qd, ldq_d, il, iu) != 0) {
+            printf(" eigsolve error: device tridiagonal eigensolver failed! (batch problem %d)\n", q);
+            infos[q] = -1;
+            bad = 1;
+            return false;
+        }
+        EIG_HIP(hipMemcpyAsync(w_h[q], w_d[q], sizeof(double) * N, hipMemcpyDeviceToHost, st));
+        return true;
+    };
+    if (zipC && nprob > 1) {
+        // the tridiagonal eigensolvers of a group one after the other (host-side deflation scans in between), each into slots of its
+        // own; then the back-transformations and final solves of the group as one zipped sequence
+        for (int q0 = 0; q0 < nprob; q0 += 4) {
+            const int nq = std::min(4, nprob - q0);
+            int good[4], ng = 0;
+            double* Qd[4];
+            int ldq_d[4];
+            for (int j = 0; j < nq; ++j) {
+                const int q = q0 + j;
+                if (infos[q] != 0) continue;
+                c.grp_q = j;
+                const bool ok = tridiag(q, &Qd[ng], &ldq_d[ng]);
+                c.grp_q = 0;
+                if (ok) good[ng++] = q;
             }
+            if (ng == 0) continue;
+            // (grouped() numbers the group's scratch slots 0 .. ng-1: the eigenvectors of T stay where their solver put them)
+            grouped(ng, [&](int j) { tail(good[j], Qd[j], ldq_d[j]); });
+            for (int j = 0; j < ng; ++j) host_copy(good[j]);
+        }
+    } else {
+        for (int q = 0; q < nprob; ++q) {
+            if (infos[q] != 0) continue;
+            double* Qd = nullptr;
+            int ldq_d = 0;
+            if (!tridiag(q, &Qd, &ldq_d)) continue;
+            tail(q, Qd, ldq_d);
+            host_copy(q);
         }
     }
     c.sync(st);

@@ -41,6 +41,9 @@ __device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel
 #define TSTAMP(KID, PH, T0) do { } while (0)
 #define TSTAMPW(KID, PH, T0, W) do { } while (0)
 #endif
+#ifndef EIG_MV_SNAKE
+#define EIG_MV_SNAKE 1    // the mat-vec's tiles walked in alternating direction from column to column (0: always ascending, rounds 1-5)
+#endif
 #ifndef EIG_MV_PADLDS
 #define EIG_MV_PADLDS 0   // (measurement variant: the register-staged kernel with the LDS footprint of the DMA form)
 #endif
@@ -437,7 +440,17 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
     // ---------------- Hermitian mat-vec tiles: the four streaming waves ----------------
     const int nt = (n + HT - 1) / HT;
     const int ntiles = nt * (nt + 1) / 2;
-    int I = 0, J = 0, t = hb;
+    // Workgroup hb owns the tiles hb, hb + gh, hb + 2 gh, ... -- the same tiles in every column of the sweep (and, the grid being a
+    // multiple of 8, on the same XCD).  It walks them in ALTERNATING direction from column to column (round 6): what a column reads
+    // last is what the next column reads first, i.e. the part of the stream that is still in that XCD's 4 MB L2 (L2 contents survive
+    // kernel boundaries, profiles/r04_experiments.txt 15; walked in one direction an LRU cache smaller than the stream never hits).
+    // Every tile writes its own slots of the partial array, so only the order of the per-workgroup sum S changes with the direction.
+    const int KT = (hb < ntiles && !is_gemv) ? (ntiles - hb + a.gh - 1) / a.gh : 0;
+    // (only where the launch's stream exceeds what the L2s keep anyway: below ~24 MB every order hits, and the ascending one measured
+    //  2 % faster there -- dsytrd N=2048 sweep 9.26 vs 9.46 ms)
+    const bool rev = EIG_MV_SNAKE && !plain && (i & 1) && (size_t)ntiles * NB * (HT * HT * sizeof(T)) > ((size_t)24 << 20);
+    auto tile_at = [&](int k) -> int { return hb + (rev ? KT - 1 - k : k) * a.gh; };
+    int I = 0, J = 0, t = KT > 0 ? tile_at(0) : ntiles;
     if constexpr (DMA) {
         if (wave < 4) {
             // Streaming waves, LDS-DMA form: DEPTH wave-tiles in flight per wave whatever the wave computes meanwhile.  Per tile:
@@ -493,16 +506,16 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
             //  profiles/r06_experiments.txt section 1.)
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d)
-                if (t + d * a.gh < ntiles) issue(d, t + d * a.gh);
+                if (d < KT) issue(d, tile_at(d));
             TSTAMP(0, 0, T0);   // first DEPTH tiles requested
             int k = 0;
-            while (t < ntiles) {
+            while (k < KT) {
                 tile_decode(t, I, J);
                 const int r0 = I * HT, c0 = J * HT;
                 const bool diag = (I == J);
                 const int r = r0 + lane;
                 const int rb = k & 1, xs = k % 3, slot = k & (DEPTH - 1);
-                const int ahead = min(DEPTH - 1, (ntiles - 1 - t) / a.gh);   // younger tiles of this wave in flight
+                const int ahead = min(DEPTH - 1, KT - 1 - k);   // younger tiles of this wave in flight
                 if (ahead == 0) wait_vmcnt<0>();
                 else if (ahead == 1) wait_vmcnt<RG::NDT>();
                 else if (ahead == 2) wait_vmcnt<2 * RG::NDT>();
@@ -515,7 +528,7 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
                 const T xc_raw = sp[16 * HT + lane], xr_raw = sp[17 * HT + lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot is in registers: it may be overwritten
                 if (k == 0) TSTAMP(0, 6, T0);   // ... and copied into registers
-                if (t + DEPTH * a.gh < ntiles) issue(slot, t + DEPTH * a.gh);
+                if (k + DEPTH < KT) issue(slot, tile_at(k + DEPTH));
                 if (k == 0) TSTAMP(0, 7, T0);   // ... slot handed back to the DMA
                 xcs[xs][lane] = sel(c0 + lane < nz, xc_raw, zero);
                 const T xr = sel(r < nz, xr_raw, zero);
@@ -528,8 +541,8 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
                 if (k == 0) { TSTAMP(0, 3, T0); TSTAMPW(2, 0, T0, 3); }   // first tile multiplied: wave 0, wave 3
                 redy[rb][wave][lane] = yI;
                 if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
-                t += a.gh;
                 ++k;
+                t = k < KT ? tile_at(k) : ntiles;
                 __syncthreads();
                 if (k == 1) TSTAMP(2, 1, T0);   // first barrier passed (streaming wave 0)
             }
@@ -559,7 +572,7 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
         __syncthreads();
         TSTAMP(0, 1, T0);
         int k = 0;
-        while (t < ntiles) {
+        while (k < KT) {
             const int r0 = I * HT, c0 = J * HT;
             const bool diag = (I == J);
             const int r = r0 + lane;
@@ -571,8 +584,8 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
             TSTAMP(0, 3, T0);   // tile loads arrived, FMAs + transpose-reduce done
             redy[rb][wave][lane] = yI;
             if ((lane & 3) == 0) redt[rb][wave * 16 + transpose_col_of_lane(lane)] = tval;
-            t += a.gh;
             ++k;
+            t = k < KT ? tile_at(k) : ntiles;
             if (t < ntiles) issue_tile(k % 3);   // next tile's loads fly while wave 4 finishes this one
             TSTAMP(0, 4, T0);
             __syncthreads();
@@ -668,14 +681,14 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
     TSTAMPW(0, 2, T0, 4);
     T Sacc = Tr<T>::zero();
     int k = 0;
-    while (t < ntiles) {
+    while (k < KT) {
         const int r0 = I * HT, c0 = J * HT, Ic = I, Jc = J;
         const bool diag = (I == J);
         const int r = r0 + lane;
         const T xr = sel(r < nz, xr_raw, zero);
         T lastc = sel(!plain && J == nt - 1 && r <= n - 1, lc_raw, zero);
         lastc = sel(r == n - 1, Tr<T>::realpart(lastc), lastc);
-        t += a.gh;
+        t = k + 1 < KT ? tile_at(k + 1) : ntiles;
         if (t < ntiles) issue_mine();
         __syncthreads();   // partial sums of tile k are in redy / redt [k & 1]
         if (k == 0) TSTAMPW(2, 3, T0, 4);   // finishing wave: first barrier passed

@@ -1250,7 +1250,9 @@ def test_baseline_config_vs_lapack_fixture(env, golden_dir, cfg, fam):
     else:   # reference recipe: judged against LAPACK on the same input
         assert res <= max(n * EPS, 4 * lap_res), (res, lap_res)
         assert bortho <= max(1e-10, 10 * lap_bo), (bortho, lap_bo)
-        assert l2w <= 1e-8      # the lowest quarter of the spectrum is insensitive to the factor's rounding
+        # two backward-stable solvers agree in the eigenvalues to ~cond(B) eps (w_tol above); the lowest quarter of the spectrum is far
+        # less sensitive to the factor's rounding than that bound, which the largest eigenvalues set
+        assert l2w <= w_tol(oracle.herm_from_upper(B), 1e-8), (l2w, w_tol(oracle.herm_from_upper(B), 1e-8))
 
 
 def test_c5_full_size_batch_all_64_problems(env, golden_dir):
