@@ -47,6 +47,22 @@ __device__ unsigned long long g_trd_count[4];       // kernel 0: panel_mv_kernel
 #ifndef EIG_MV_PADLDS
 #define EIG_MV_PADLDS 0   // (measurement variant: the register-staged kernel with the LDS footprint of the DMA form)
 #endif
+// The partial sums P the mat-vec hands to the next row kernel, stored / loaded with the non-temporal hint (EIG_MV_NT_P = 1): they are
+// written once and read once, and with the alternating tile order every L2 line they do not take is a line of the matrix stream
+// that the next column finds.
+#ifndef EIG_MV_NT_P
+#define EIG_MV_NT_P 0
+#endif
+typedef double d2v_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_p(double* p, double v) { if (EIG_MV_NT_P) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void st_p(cplx* p, cplx v) {
+    if (EIG_MV_NT_P) __builtin_nontemporal_store(d2v_{v.x, v.y}, reinterpret_cast<d2v_*>(p)); else *p = v;
+}
+__device__ __forceinline__ double ld_p(const double* p) { return EIG_MV_NT_P ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ cplx ld_p(const cplx* p) {
+    if (EIG_MV_NT_P) { const d2v_ v = __builtin_nontemporal_load(reinterpret_cast<const d2v_*>(p)); return cplx{v.x, v.y}; }
+    return *p;
+}
 constexpr int HT = 64;     // hemv tile: 64 rows x 64 cols per workgroup step (one row per lane)
 constexpr int CH = 512;    // rows per gemv partial chunk (8 rows per lane)
 constexpr int NBMAX = 64;  // maximum panel width
@@ -164,7 +180,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelBatch<T, NB> ab) {
             const int kl = min(c + 1 + kz, a.np - 1);
             l_ww = a.W[(size_t)i + (size_t)(kl - wbase) * a.ldw];
             l_wv = a.A[(size_t)i + (size_t)kl * a.lda];
-            l_p0 = a.P[(size_t)min(lane, ntc - 1) * a.ldp + i];
+            l_p0 = ld_p(&a.P[(size_t)min(lane, ntc - 1) * a.ldp + i]);
         }
         // (b) partial sums gathered by the workgroup: stacked gemv and v^H A v
 #pragma unroll
@@ -179,7 +195,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelBatch<T, NB> ab) {
             tw[u] = a.W[rc + (size_t)(k - wbase) * a.ldw];
         }
 #pragma unroll
-        for (int u = 0; u < RP; ++u) pt[u] = a.P[(size_t)min(g + RG * u, ntc - 1) * a.ldp + rc];
+        for (int u = 0; u < RP; ++u) pt[u] = ld_p(&a.P[(size_t)min(g + RG * u, ntc - 1) * a.ldp + rc]);
         vr = a.A[rc + (size_t)c * a.lda];
     }
     if constexpr (do_update) acur = a.A[rc + (size_t)i * a.lda];
@@ -215,7 +231,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelBatch<T, NB> ab) {
         if constexpr (do_update) {
             const T wi_w = sel(lane < npo, l_ww, zero), wi_v = sel(lane < npo, l_wv, zero);
             T wi_p = sel(lane < ntc, l_p0, zero);
-            for (int q = lane + 64; q < ntc; q += 64) wi_p = wi_p + a.P[(size_t)q * a.ldp + i];   // N > 4096 only
+            for (int q = lane + 64; q < ntc; q += 64) wi_p = wi_p + ld_p(&a.P[(size_t)q * a.ldp + i]);   // N > 4096 only
             const T u = wave_sum(wi_p - (wi_w * z1l + wi_v * z2l));
             const T wi = tau * u + alpha * vic;
             if (lane < npo) { rowW[wave][lane] = conj_(wi_w); rowV[wave][lane] = conj_(wi_v); }
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(256) panel_row_kernel(PanelBatch<T, NB> ab) {
         }
 #pragma unroll
         for (int u = 0; u < RP; ++u) acc2 = acc2 + sel((g + RG * u < ntc) && active, pt[u], zero);
-        for (int q = g + RG * RP; q < ntc; q += RG) acc2 = acc2 + sel(active, a.P[(size_t)q * a.ldp + rc], zero);
+        for (int q = g + RG * RP; q < ntc; q += RG) acc2 = acc2 + sel(active, ld_p(&a.P[(size_t)q * a.ldp + rc]), zero);
     }
     TSTAMP(1, 3, T0);       // row data arrived, slices done
     const T urow = row_sum16(acc2);
@@ -699,12 +715,12 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
         T vJ = scale * xcs[xs][lane] + unit(c0 + lane);
         if (diag) {
             T s = yv + tv;
-            a.P[(size_t)Jc * a.ldp + r0 + lane] = s;
+            st_p(&a.P[(size_t)Jc * a.ldp + r0 + lane], s);
             fmac_(Sacc, vI, s);
             if (!plain && c0 + lane < n) a.A[(size_t)(c0 + lane) + (size_t)i * a.lda] = vJ;
         } else {
-            a.P[(size_t)Jc * a.ldp + r0 + lane] = yv;
-            a.P[(size_t)Ic * a.ldp + c0 + lane] = tv;
+            st_p(&a.P[(size_t)Jc * a.ldp + r0 + lane], yv);
+            st_p(&a.P[(size_t)Ic * a.ldp + c0 + lane], tv);
             fmac_(Sacc, vI, yv);
             fmac_(Sacc, vJ, tv);
         }
