@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(int M, int N, int sp
 
 // Split-K partial sums live in a per-stream scratch slot: with the two-stream overlap options gemms on c.s1 and c.s2
 // may both take the split path at the same time.
-static const char* splitk_slot(const Ctx& c, hipStream_t st) { return (c.s2 && st == c.s2) ? "splitk_s2" : "splitk"; }
+static const char* splitk_slot(const Ctx& c, hipStream_t st) { return (c.s2 && st == c.s2) ? "splitk_s2" : ((c.s3 && st == c.s3) ? "splitk_s3" : "splitk"); }
 
 // Host side of tile_of: the map for a tm x tn tile grid (tri: only the stored triangle of a square grid is launched).
 // Super-tile shapes of 64 tiles; the one that pads the grid least wins, squarer shapes preferred (2 % per factor of two
@@ -2121,9 +2121,26 @@ template <class T> void build_invU(Ctx& c, hipStream_t st, int N, const T* U, in
 // block rows kb0 .. kb1-1 of the right-looking factorization of nprob (<= 4) matrices of one order in lockstep: ONE block-row
 // launch per block row for all of them (blockIdx.y = problem), one rank-64 update per problem.  `expect`: the cumulative
 // announce count of chol_row_kernel; info0 / loaded0: nprob consecutive words each, zeroed by the caller.
+// Look-ahead (option "overlap" bit 2, round 6; one problem that has the device to itself).  The rank-128 update behind a pair of
+// block rows is split into the two block rows the NEXT pair factors (a 128-row strip, queued on the chain's stream) and the rest
+// (queued on a third stream behind an event): the next pair's latency-bound block-row kernels (2 x 33 us with <= 64 workgroups
+// resident) run beside the rest update of this pair instead of behind it.  Dependencies: the strip of pair k+1 is also touched by
+// the rest update of pair k-1..0, so the chain waits for the previous rest update before it applies the strip update (evU); the
+// rest update reads the pair's finished block rows (evC).  Every element still receives its updates in the order of the pairs and
+// each update is the same K = 128 sum: bit-identical to the one-stream form.
+struct LookAhead {
+    hipStream_t sB = nullptr;
+    hipEvent_t evC = nullptr, evU = nullptr;
+    bool pending = false;        // a rest update is in flight on sB (evU recorded behind it)
+};
+constexpr int kLookAheadMinRest = 1024;    // order of the rest update below which the split does not pay
+static void lookahead_join(LookAhead* la, hipStream_t st) {
+    if (la && la->pending) { EIG_HIP(hipStreamWaitEvent(st, la->evU, 0)); la->pending = false; }
+}
+
 template <class T>
 static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const* B, int ldb, int kb0, int kb1, unsigned& expect,
-                             int* info0, unsigned* loaded0) {
+                             int* info0, unsigned* loaded0, LookAhead* la = nullptr) {
     CholBatch<T> cb;
     for (int q = 0; q < CHOL_MAXB; ++q) cb.B[q] = B[q < nprob ? q : 0];
     if (c.potrf_mode >= 2) {
@@ -2140,6 +2157,7 @@ static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const*
             if (rem <= 0) break;
             const int k1 = k0 + nb;
             if (kb + 1 >= kb1) {       // (odd number of block rows in this range: plain rank-64 update)
+                lookahead_join(la, st);
                 for (int q = 0; q < nprob; ++q) {
                     const T* B12 = B[q] + (size_t)k0 + (size_t)k1 * ldb;
                     gemm<T>(c, st, rem, rem, nb, Tr<T>::make(-1.0, 0.0), opA('C', B12, ldb), opB('N', B12, ldb), Tr<T>::one(),
@@ -2158,10 +2176,26 @@ static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const*
             hipLaunchKernelGGL((chol_row2_kernel<T>), dim3(1 + chunks, nprob), dim3(256), 0, st, N, cb, ldb, k1, info0, loaded0, expect);
             if (rem1 > 0) {
                 const int k2 = k1 + nb1;
-                for (int q = 0; q < nprob; ++q) {
-                    const T* B13 = B[q] + (size_t)k0 + (size_t)k2 * ldb;
-                    gemm<T>(c, st, rem1, rem1, nb + nb1, Tr<T>::make(-1.0, 0.0), opA('C', B13, ldb), opB('N', B13, ldb), Tr<T>::one(),
-                            B[q] + (size_t)k2 + (size_t)k2 * ldb, ldb, e);
+                const int nbn = min(2 * DB, rem1);      // the block rows of the next pair
+                if (la && nprob == 1 && rem1 - nbn >= kLookAheadMinRest) {
+                    const T* B13 = B[0] + (size_t)k0 + (size_t)k2 * ldb;
+                    EIG_HIP(hipEventRecord(la->evC, st));                                  // block rows k0, k1 are final
+                    lookahead_join(la, st);                                                // (the previous rest update reached into the strip)
+                    gemm<T>(c, st, nbn, rem1, nb + nb1, Tr<T>::make(-1.0, 0.0), opA('C', B13, ldb), opB('N', B13, ldb), Tr<T>::one(),
+                            B[0] + (size_t)k2 + (size_t)k2 * ldb, ldb, e);                 // the strip: rows k2 .. k2 + nbn - 1
+                    EIG_HIP(hipStreamWaitEvent(la->sB, la->evC, 0));
+                    const T* B13r = B13 + (size_t)nbn * ldb;
+                    gemm<T>(c, la->sB, rem1 - nbn, rem1 - nbn, nb + nb1, Tr<T>::make(-1.0, 0.0), opA('C', B13r, ldb), opB('N', B13r, ldb),
+                            Tr<T>::one(), B[0] + (size_t)(k2 + nbn) + (size_t)(k2 + nbn) * ldb, ldb, e);   // everything below the strip
+                    EIG_HIP(hipEventRecord(la->evU, la->sB));
+                    la->pending = true;
+                } else {
+                    lookahead_join(la, st);
+                    for (int q = 0; q < nprob; ++q) {
+                        const T* B13 = B[q] + (size_t)k0 + (size_t)k2 * ldb;
+                        gemm<T>(c, st, rem1, rem1, nb + nb1, Tr<T>::make(-1.0, 0.0), opA('C', B13, ldb), opB('N', B13, ldb), Tr<T>::one(),
+                                B[q] + (size_t)k2 + (size_t)k2 * ldb, ldb, e);
+                    }
                 }
             }
         }
@@ -2185,9 +2219,22 @@ static void potrf_block_rows(Ctx& c, hipStream_t st, int N, int nprob, T* const*
     }
     EIG_HIP(hipGetLastError());
 }
-template <class T> static void potrf_block_rows(Ctx& c, hipStream_t st, int N, T* B, int ldb, int kb0, int kb1, unsigned& expect) {
+template <class T> static void potrf_block_rows(Ctx& c, hipStream_t st, int N, T* B, int ldb, int kb0, int kb1, unsigned& expect,
+                                                LookAhead* la = nullptr) {
     T* one[1] = {B};
-    potrf_block_rows<T>(c, st, N, 1, one, ldb, kb0, kb1, expect, c.d_info, reinterpret_cast<unsigned*>(c.d_info) + 2);
+    potrf_block_rows<T>(c, st, N, 1, one, ldb, kb0, kb1, expect, c.d_info, reinterpret_cast<unsigned*>(c.d_info) + 2, la);
+}
+// the look-ahead state of a factorization on stream st, or "none" (la.sB stays null): one problem, alone on the device, block-row
+// pairs, large enough for at least one split update
+static bool lookahead_begin(Ctx& c, int N, LookAhead& la) {
+    if (!(c.overlap & 4) || c.in_batch || c.rec || c.potrf_mode < 2 || N < kLookAheadMinRest + 4 * DB) return false;
+    if (streams_in_use(c.dev) > c.own_streams()) return false;
+    for (auto& e : c.evLA)
+        if (!e) EIG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    la.sB = c.third_stream();
+    la.evC = c.evLA[0]; la.evU = c.evLA[1];
+    la.pending = false;
+    return true;
 }
 
 // The factorizations of a lockstep group (batch calls): block rows only -- the inverse diagonal blocks live in ONE set of scratch
@@ -2215,7 +2262,10 @@ template <class T> void potrf_upper(Ctx& c, hipStream_t st, int N, T* B, int ldb
         potrf_rec(c, st, N, N, 0, B, ldb, invU);
     } else {
         unsigned expect = 0;
-        potrf_block_rows<T>(c, st, N, B, ldb, 0, nblk, expect);
+        LookAhead la;
+        const bool use_la = lookahead_begin(c, N, la);
+        potrf_block_rows<T>(c, st, N, B, ldb, 0, nblk, expect, use_la ? &la : nullptr);
+        lookahead_join(use_la ? &la : nullptr, st);
         build_invU<T>(c, st, N, (const T*)B, ldb);
     }
     build_inv_blocks<T>(c, st, N, (const T*)B, ldb);
@@ -2481,13 +2531,16 @@ template <class T> void potrf_hegst_pipelined_begin(Ctx& c, int N, T* A, int lda
     EIG_HIP(hipMemsetAsync(c.d_info, 0, 4 * sizeof(int), s1));
     unsigned expect = 0;
     constexpr int SB = kStageRows / DB, SG = kStageRows / BB;
+    LookAhead la;
+    const bool use_la = lookahead_begin(c, N, la);     // (the rest updates only touch rows below the stage being factored)
     for (int s_ = 0; s_ < nstage; ++s_) {
         const int kb0 = s_ * SB, kb1 = min(nblk, kb0 + SB), g0 = s_ * SG, g1 = min(ngall, g0 + SG);
-        potrf_block_rows<T>(c, s1, N, B, ldb, kb0, kb1, expect);
+        potrf_block_rows<T>(c, s1, N, B, ldb, kb0, kb1, expect, use_la ? &la : nullptr);
         build_invU_range<T>(c, s1, N, (const T*)B, ldb, kb0, kb1 - kb0);
         build_inv256_groups<T>(c, s1, N, (const T*)B, ldb, g0, g1 - g0);
         EIG_HIP(hipEventRecord(c.evStage[s_], s1));   // rows < (s_+1) * 1024 of U and their inverse diagonal blocks are final
     }
+    lookahead_join(use_la ? &la : nullptr, s1);
     // (everything above is queued before the first wait below is: a wait on an event that has not been recorded yet is a no-op)
     hipStream_t s2 = c.second_stream();
     hegst_pregrow<T>(c, N);

@@ -114,7 +114,7 @@ constexpr int kTridiagDefault = 1;
 // 64-blocks whose T factors are merged pairwise (bt_build_T in evd.hip): K of the rank-k updates grows with the block.
 constexpr int kBtNbDefault = 256;
 inline int norm_bt_nb(int v) { return v <= 0 ? kBtNbDefault : (v >= 512 ? 512 : (v >= 256 ? 256 : (v >= 128 ? 128 : 64))); }
-constexpr int kOverlapDefault = 3;
+constexpr int kOverlapDefault = 3;   // (bit 2, the look-ahead factorization, is built and bit-identical but gains nothing: profiles/r06_experiments.txt 7)
 constexpr int kPotrfDefault = 2;
 // Largest library-side copy of the standard problem's eigenvectors (N x m, MiB) the generalized drivers allocate; beyond it (or when
 // that much device memory is not available) the vectors are formed in the caller's Z and the final triangular solve runs in column
@@ -152,6 +152,8 @@ struct Ctx {
     hipEvent_t evSync = nullptr;
     hipEvent_t ev[2 * PH_COUNT] = {};
     hipEvent_t evA = nullptr, evB = nullptr;
+    hipStream_t s3 = nullptr;  // third stream: the trailing updates of the look-ahead factorization ("overlap" bit 2), leased like s2
+    hipEvent_t evLA[2] = {};   // look-ahead factorization: block rows of a pair done (chain -> updates), update done (updates -> chain)
     hipEvent_t evStage[16] = {};   // block-row stages of the factorization (potrf || hegst pipeline), created on first use
     std::map<std::string, std::pair<void*, size_t>> slots;  // named grow-only device scratch
     // Lockstep groups of a batch call (hegvdx_batch_core in evd.hip): while `rec` is set the BLAS-3 drivers append their launches to it
@@ -221,6 +223,8 @@ struct Ctx {
     void sync(hipStream_t st);
     void sync() { sync(s1); }
     hipStream_t second_stream();
+    hipStream_t third_stream();
+    int own_streams() const { return 1 + (s2 ? 1 : 0) + (s3 ? 1 : 0); }   // streams this context holds from the pool
     void drop_graphs();   // forget captured launch sequences (an option they bake in has changed)
 };
 

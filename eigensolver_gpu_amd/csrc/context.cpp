@@ -112,6 +112,7 @@ static void* scratch_grow(Ctx& c, const char* name0, size_t bytes, bool may_fail
         if (s.first) {
             if (c.lease_depth > 0) c.sync(c.s1);     // (outside a call nothing of this context is in flight: calls end synchronised)
             if (c.s2) EIG_HIP(hipStreamSynchronize(c.s2));
+            if (c.s3) EIG_HIP(hipStreamSynchronize(c.s3));
             void* old = s.first;
             s.first = nullptr; s.second = 0;   // (a failing hipMalloc below must not leave a dangling pointer in the slot)
             EIG_HIP(hipFree(old));
@@ -158,6 +159,11 @@ StreamLease::~StreamLease() {
             return_stream(c.dev, c.s2);
             c.s2 = nullptr;
         }
+        if (c.s3) {
+            (void)hipStreamSynchronize(c.s3);
+            return_stream(c.dev, c.s3);
+            c.s3 = nullptr;
+        }
         return_stream(c.dev, c.s1);
     }
 }
@@ -176,6 +182,10 @@ hipStream_t Ctx::second_stream() {
     if (!s2) s2 = lease_stream(dev, nullptr);
     return s2;
 }
+hipStream_t Ctx::third_stream() {
+    if (!s3) s3 = lease_stream(dev, nullptr);
+    return s3;
+}
 
 void Ctx::drop_graphs() {
     if (graphs.empty()) return;
@@ -191,6 +201,7 @@ void Ctx::release() {
     if (hipGetDevice(&cur) != hipSuccess) return;   // runtime already gone (process teardown): nothing to free
     if (dev >= 0 && cur != dev) (void)hipSetDevice(dev);
     if (s2) (void)hipStreamSynchronize(s2);
+    if (s3) (void)hipStreamSynchronize(s3);
     drop_graphs();
     for (auto& kv : slots)
         if (kv.second.first) (void)hipFree(kv.second.first);
@@ -203,14 +214,16 @@ void Ctx::release() {
     if (evA) (void)hipEventDestroy(evA);
     for (auto& e : evStage) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (evB) (void)hipEventDestroy(evB);
+    for (auto& e : evLA) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (d_info) (void)hipFree(d_info);
     if (h_info) (void)hipHostFree(h_info);
     if (evSync) (void)hipEventDestroy(evSync);
     evSync = nullptr;
     // s1 belongs to the stream pool: never destroyed
     if (s2) return_stream(dev, s2);   // (pool streams live until eigsolve_finalize)
+    if (s3) return_stream(dev, s3);
     for (auto& e : ev) e = nullptr;
-    evA = evB = nullptr; d_info = nullptr; h_info = nullptr; s1 = s2 = nullptr;
+    evA = evB = nullptr; d_info = nullptr; h_info = nullptr; s1 = s2 = s3 = nullptr;
     if (dev >= 0 && cur != dev) (void)hipSetDevice(cur);
 }
 
@@ -381,7 +394,7 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "hemv_blocks") { c.hemv_blocks = value < 0 ? 0 : (value > kHemvBlocksMax ? kHemvBlocksMax : value); c.drop_graphs(); }
     else if (s == "real_il_reference") c.real_il_reference = value > 0;
     else if (s == "graph") c.use_graph = value > 0;
-    else if (s == "overlap") c.overlap = value < 0 ? kOverlapDefault : (value & 3);
+    else if (s == "overlap") c.overlap = value < 0 ? kOverlapDefault : (value & 7);
     else if (s == "trsm_base") c.trsm_base = value <= 0 ? kTrsmBaseDefault : norm_trsm_base(value);
     else if (s == "potrf") c.potrf_mode = value == 0 ? 0 : (value == 1 ? 1 : kPotrfDefault);
     else if (s == "gst") c.gst_mode = (value < 0 || value > 3) ? kGstModeDefault : value;

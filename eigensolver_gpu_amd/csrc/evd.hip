@@ -341,7 +341,7 @@ static int heevd_core(Ctx& c, int il, int iu, int N, T* A, int lda, T* Z, int ld
     // eigenproblem is being solved (zheevd_gpu.F90:125 does the same per block with stream1/stream2)
     // Only for a solve that has the device to itself, and only ENQUEUED once the tridiagonalization has finished: a queue that sits
     // blocked on an event while the per-column kernels run costs every one of their dispatches ~1 us (measured: trd + 4.7 ms).
-    const bool ovT = (c.overlap & 2) != 0 && !c.in_batch && streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
+    const bool ovT = (c.overlap & 2) != 0 && !c.in_batch && streams_in_use(c.dev) <= c.own_streams();
     auto build_T_beside = [&]() {
         hipStream_t stT = c.second_stream();
         bt_build_T<T>(c, stT, N, Vsrc, ldv, tau_bt, c.bt_nb);
@@ -437,7 +437,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     const int m = iu - il + 1;
     // potrf || the U11-only part of hegst (blas3.hip: potrf_hegst_pipelined_begin) when this solve has the device to itself;
     // phase times: "potrf" = until the factor is complete, "gst" = what is left of hegst after that.
-    const bool pipe = (c.overlap & 1) && !c.in_batch && pipeline_applicable<T>(c, N) && streams_in_use(c.dev) <= (c.s2 ? 2 : 1);
+    const bool pipe = (c.overlap & 1) && !c.in_batch && pipeline_applicable<T>(c, N) && streams_in_use(c.dev) <= c.own_streams();
     // Cholesky of B (zhegvdx_gpu.F90:135-142)
     {
         PhaseRange r(Tr<T>::cx ? "cusolverdnZpotrf" : "cusolverdnDpotrf");   // the reference's range name, :134
@@ -501,7 +501,7 @@ static int hegvdx_core(Ctx& c, int N, T* A, int lda, T* B, int ldb, T* Z, int ld
     // (Splitting the COLUMNS instead changes the split-K decisions of the products, and at m = 1024 half-width solves lose what the
     //  copy gains -- round 3.)
     const bool zoverlap = !skip_host_copy && !chunked && (long)N * m >= (long)EIG_ZOVERLAP_MIN && (c.overlap & 2) && !c.in_batch &&
-                          streams_in_use(c.dev) <= (c.s2 ? 2 : 1) && host_ptr_is_pinned(Z_h);
+                          streams_in_use(c.dev) <= c.own_streams() && host_ptr_is_pinned(Z_h);
     bool copy_failed = false;
     {
         PhaseRange r(Tr<T>::cx ? "cublasZtrsm" : "cublasDtrsm");   // :167

@@ -62,7 +62,9 @@ int eigsolve_set_host_threads(int nthreads);
  *   "overlap"   bit mask of independent launch chains of one solve that run on a second stream (leased from the library's
  *               stream pool for the call): bit 0 = hegst beside the factorization, released stage by stage, bit 1 = larft T
  *               factors beside the tridiagonal eigensolver (zheevd_gpu.F90:125 overlaps the same work) and, for N*m >= 2^20,
- *               the host copy Z_h in row blocks beside the final triangular solve (zhegvdx_gpu.F90:169-180).  Default 3.  Same
+ *               the host copy Z_h in row blocks beside the final triangular solve (zhegvdx_gpu.F90:169-180), bit 2 = look-ahead
+ *               in the Cholesky factorization (the block rows of the next pair beside the rank-128 update of the rest, third
+ *               stream; measured: no gain, the block-row kernel needs whole CUs and the update holds them all).  Default 3.  Same
  *               kernels, operands and order of operations per block: results are bit-identical to "overlap" 0.  Only applied
  *               to a solve that has the device to itself (best effort: no other call of this library in flight, not inside a
  *               batch call).

@@ -925,18 +925,20 @@ def test_optional_execution_modes_are_bit_identical(env, cplx, opt, n, m):
     torch, oracle, api = env
     A = oracle.gen_spd_fast(n, 4000 + n, cplx)
     B = oracle.gen_spd_fast(n, 5000 + n, cplx, shift=float(n))
-    on = 1 if opt == "graph" else 3
+    on = 1 if opt == "graph" else 7
     out = {}
     try:
-        for mode in (0, on, on):   # the second run replays a cached graph / re-leases the pooled second stream
+        for mode in (0, on, on) if opt == "graph" else (0, 7, 7, 4, 3):   # the second run replays a cached graph / re-leases the pooled streams;
+                                                                       # 4 = the look-ahead factorization alone (third stream), 3 = the round-3 pair
             assert api.set_option(opt, mode) == 0
             info, ws, w, Z = run_driver(api, np.triu(A), np.triu(B), 1, m)
             assert info == 0
             out.setdefault(mode, []).append((w, Z))
     finally:
         api.set_option(opt, 0 if opt == "graph" else -1)
-    for w, Z in out[on]:
-        assert np.array_equal(out[0][0][0], w) and np.array_equal(out[0][0][1], Z)
+    for mode in out:
+        for w, Z in out[mode]:
+            assert np.array_equal(out[0][0][0], w) and np.array_equal(out[0][0][1], Z), mode
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -1406,7 +1408,7 @@ def test_overlap_option_with_split_k_sizes(env):
     B = oracle.gen_spd_fast(n, 5400 + n, True, shift=float(n))
     out = []
     try:
-        for mode in (0, 1, 3, 3):
+        for mode in (0, 1, 3, 3, 7, 4):
             api.set_option("overlap", mode)
             info, ws = api.hegvdx(api.to_device(np.triu(A)), api.to_device(np.triu(B)), 1, m)
             assert info == 0
