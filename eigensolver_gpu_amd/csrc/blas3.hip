@@ -574,11 +574,18 @@ struct DmaTile {
     int moffA, moffB;
 };
 
-template <bool MASKED>
-__global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int gx, int gy, int gz, int persistent) {
+// LEAN form (BK = 8, WPC = 3): slabs half as deep -- 16 KB per stage, 32 KB per workgroup -- and the C tile fetched in the epilogue,
+// one 16 x 16 block at a time, instead of being held beside the accumulators: <= 168 VGPRs, THREE workgroups per CU.  For the
+// short-K updates (her2k / the rank-128 updates of the factorization: 4-8 slabs of 16 per tile) the fixed part of a tile -- first
+// slab latency, C read-modify-write: 7.7 us of a 25 us tile round at K = 64 -- is then covered by the MFMAs of two other workgroups
+// instead of one.  Same k order, same lane mapping: bit-identical to the other forms.
+template <bool MASKED, int BK, int WPC>
+__global__ void __launch_bounds__(256, WPC) gemm_dma_kernel(GemmArgs<cplx> g, int gx, int gy, int gz, int persistent) {
     using T = cplx;
-    constexpr int BM = 64, BN = 64, BK = BKL, NPL = 2;
-    constexpr int OPB = BK * 64 * 16;     // bytes of one operand's slab: 16 fragment blocks
+    constexpr int BM = 64, BN = 64, NPL = 2;
+    constexpr bool LEAN = WPC > 2;
+    constexpr int BPW = BK / 4;           // fragment blocks per operand, slab and wave
+    constexpr int OPB = BK * 64 * 16;     // bytes of one operand's slab: BK fragment blocks
     constexpr int STG = 2 * OPB;
     constexpr int WM = 32, WN = 32, TM = 2, TN = 2;
     __shared__ __attribute__((aligned(1024))) unsigned char sm[2 * STG];
@@ -700,24 +707,26 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
         if (o.mask == M_LOWER) return dmin < 0;
         return dmax - moff >= 0;
     };
-    // wave w requests the fragment blocks (kb = w, ib = 0..3) of both operands: 8 instructions per slab and wave
+    // wave w requests the fragment blocks b = w * BPW .. (kb = b / 4, ib = b % 4) of both operands: 2 * BPW instructions per slab and wave
+    // (BK = 16: kb = w, ib = 0..3)
     auto request_operand = [&](const Operand<T>& o, int moff, const T* p, long ld, int x0, int xmax, int kl, int ke, unsigned dst) {
         const long sidx = o.trans ? ld : 1, sk = o.trans ? 1 : ld;
-        const int kk = kl + wave * 4 + fk;                                   // this lane's k inside the segment
+        const int b0 = wave * BPW;
+        const int kk = kl + (b0 >> 2) * 4 + fk;                              // this lane's k inside the segment
         const bool need = mask_active(o, moff, x0, 64, kl);
         if (!need && x0 + 64 <= xmax && kl + BK <= ke) {                    // interior slab: two strides
-            const T* src = p + (size_t)(x0 + fi) * sidx + (size_t)kk * sk;
+            const T* src = p + (size_t)(x0 + 16 * (b0 & 3) + fi) * sidx + (size_t)kk * sk;
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) lds_dma16(src + (size_t)(16 * ib) * sidx, dst + (unsigned)((wave * 4 + ib) * 1024));
+            for (int t = 0; t < BPW; ++t) lds_dma16(src + (size_t)(16 * t) * sidx, dst + (unsigned)((b0 + t) * 1024));
         } else {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const int sx = x0 + 16 * ib + fi;
+            for (int t = 0; t < BPW; ++t) {
+                const int sx = x0 + 16 * ((b0 & 3) + t) + fi;
                 bool one;
                 const bool keep = pred(o, moff, sx, sx < xmax, kk, ke, need, one);
                 const T* src = p + (size_t)sx * sidx + (size_t)kk * sk;
                 const T* alt = reinterpret_cast<const T*>(one ? g_dma_one : g_dma_zero);
-                lds_dma16(keep ? src : alt, dst + (unsigned)((wave * 4 + ib) * 1024));
+                lds_dma16(keep ? src : alt, dst + (unsigned)((b0 + t) * 1024));
             }
         }
     };
@@ -747,8 +756,9 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
             for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int b = 0; b < TN; ++b) acc[p][a][b] = d4{0.0, 0.0, 0.0, 0.0};
-        T cv[TM][TN][4];
+        T cv[LEAN ? 1 : TM][LEAN ? 1 : TN][4];
         auto load_c = [&]() {
+            if constexpr (LEAN) return;
             const int ldc_ = cold().ldc;
 #pragma unroll
             for (int a = 0; a < TM; ++a)
@@ -760,7 +770,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
                         int gj = cur.j0 + wn0 + b * 16 + (lane >> 4) + 4 * r;
                         bool ok = gi < cur.M && gj < cur.N;
                         const T* cp = ok ? cur.pc + (size_t)gi + (size_t)gj * ldc_ : cur.pc;
-                        cv[a][b][r] = *cp;
+                        cv[LEAN ? 0 : a][LEAN ? 0 : b][r] = *cp;
                     }
         };
         auto mma_slab = [&](unsigned stage_) {
@@ -832,6 +842,17 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
         for (int a = 0; a < TM; ++a) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
+                if constexpr (LEAN) {          // C of this 16 x 16 block: fetched here (the other workgroups of the CU cover the round trip)
+                    if (use_c) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int gi = cur.i0 + wm0 + a * 16 + fi, gj = cur.j0 + wn0 + b * 16 + fk + 4 * r;
+                            const bool ok = gi < cur.M && gj < cur.N;
+                            const T* cp = ok ? cur.pc + (size_t)gi + (size_t)gj * ge.ldc : cur.pc;
+                            cv[0][0][r] = *cp;
+                        }
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int gi = cur.i0 + wm0 + a * 16 + fi;
@@ -845,7 +866,7 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
                     } else {
                         T out = scal_(al_, v);
                         if (aux && ok) aux[(size_t)gi + (size_t)gj * ge.epi.ldaux] = out;
-                        if (use_c) fma_(out, be_, cv[a][b][r]);
+                        if (use_c) fma_(out, be_, cv[LEAN ? 0 : a][LEAN ? 0 : b][r]);
                         if (ge.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
                         if (ok) cur.pc[(size_t)gi + (size_t)gj * ge.ldc] = out;
                     }
@@ -854,6 +875,254 @@ __global__ void __launch_bounds__(256, 2) gemm_dma_kernel(GemmArgs<cplx> g, int 
         }
         if (!persistent) break;
         cur = decode(cur.w + (int)gridDim.x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemm_wide_kernel -- complex 32 x 32 tiles on a workgroup of KG x 4 waves with K split INSIDE the workgroup (round 6)
+//
+// The products with fewer than one 64 x 64 tile per CU (the base cases and small updates of the triangular solves in hegst / trsm,
+// W T^H of the back-transformation, the merges of inverse blocks: ~190 launches of a C3 solve) run on 32 x 32 tiles so that a
+// launch still spans the chip.  On gemm_fast_kernel that is ONE four-wave workgroup per CU -- one wave per SIMD, every K-slab an
+// exposed global -> register -> LDS round trip between two bursts of 32 MFMAs: 1.77 us per slab of 32 for 0.85 us of MFMA work
+// (profiles/r05_pmc_summary.txt: MFMA pipe 22-28 % busy).  Here the tile gets the WHOLE CU: KG groups of four waves (2 x 2 blocks
+// of 16 x 16), group q owns the q-th part of the tile's K-slabs (contiguous, in units of slabs of 16), stages them by LDS-DMA into
+// two stages of its own (fragment-block image as in gemm_dma_kernel: 16 KB per stage), and accumulates its partial tile in
+// registers (16 VGPRs).  With KG = 4 every SIMD holds four waves whose MFMA bursts and DMA waits interleave; all of a tile's
+// K (up to 2 x KG slabs) is in flight at once.  The partial tiles are summed through LDS in the fixed order 0, 1, .., KG - 1
+// (deterministic; no partial sums in HBM, no reduce launch) and group 0 runs the epilogue.
+// The order of summation over k differs from gemm_fast_kernel's (KG chains instead of one): which kernel serves a product is a
+// function of the product's shape alone (dispatch_gemm_now), never of the execution mode, so batch / single / overlapped forms of
+// a solve stay bit-identical to each other.
+// ------------------------------------------------------------------------------------------------
+#ifndef EIG_WIDE_MFMA16
+#define EIG_WIDE_MFMA16 0
+#endif
+template <bool MASKED, int KG>
+__global__ void __launch_bounds__(256 * KG) gemm_wide_kernel(GemmArgs<cplx> g) {
+    using T = cplx;
+    constexpr int BM = 32, BN = 32, BK = BKL;
+    constexpr int OPB = BK * BM * 16;       // bytes of one operand's slab: 8 fragment blocks of 1 KB
+    constexpr int STG = 2 * OPB;            // one stage: A slab, B slab
+    constexpr int GRP = 2 * STG;            // one group's two stages
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[KG * GRP];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    typedef const __attribute__((address_space(4))) GemmArgs<cplx> ColdArgs;
+    auto cold = [&]() -> ColdArgs& {
+        ColdArgs* kp = (ColdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return *kp;
+    };
+    Operand<T> opA = g.A, opB = g.B;
+    const T *pa = g.A.p, *pb = g.B.p;
+    T* pc = g.C;
+    int gq = 0, bz = (int)blockIdx.z;
+    if (g.grp.count > 0) {                  // lockstep group: this workgroup's problem
+        ColdArgs& gc = cold();
+        gq = __builtin_amdgcn_readfirstlane(bz / gc.grp.zper);
+        bz -= gq * gc.grp.zper;
+        pa = gc.grp.Ap[gq]; pb = gc.grp.Bp[gq]; pc = gc.grp.Cp[gq];
+        opA.p2 = gc.grp.Ap2[gq]; opB.p2 = gc.grp.Bp2[gq];
+    }
+    int M = g.M, N = g.N, K = g.K, zs = bz;
+    int moffA = g.A.moff, moffB = g.B.moff;
+    if (g.bt.count > 0) {
+        const int zb = bz / g.bt.splits;
+        zs = bz - zb * g.bt.splits;
+        pa += (long)zb * g.bt.sA; pb += (long)zb * g.bt.sB; pc += (long)zb * g.bt.sC;
+        moffA += zb * g.bt.dMoffA; moffB += zb * g.bt.dMoffB;
+        K += zb * g.bt.dK;
+        if (g.bt.capK != INT_MAX) K = min(K, g.bt.capK - zb * g.bt.dcap);
+        M = min(M, g.bt.capM - zb * g.bt.dcap);
+        N = min(N, g.bt.capN - zb * g.bt.dcap);
+    }
+    int tbx, tby;
+    if (!tile_of(g, tbx, tby)) return;
+    const int i0 = tbx * BM, j0 = tby * BN;
+    if (g.epi.uplo == 1 && i0 > j0 + BN - 1) return;
+    if (g.epi.uplo == 2 && j0 > i0 + BM - 1) return;
+    if (i0 >= M || j0 >= N) return;
+    int kbeg = 0, kend = K;
+    if (g.kchunk > 0) {
+        kbeg = zs * g.kchunk;
+        kend = min(K, kbeg + g.kchunk);
+    }
+    opA.moff = moffA; opB.moff = moffB;
+    trim_k(opA, i0, BM, kbeg, kend);
+    trim_k(opB, j0, BN, kbeg, kend);
+    const bool cat = opA.k1 != INT_MAX;
+    const int k1 = cat ? opA.k1 : INT_MAX;
+    const int a1 = kbeg, b1 = min(kend, k1);
+    const int a2 = cat ? max(kbeg, k1) - k1 : 0, b2 = cat ? kend - k1 : 0;
+    const int nst1 = b1 > a1 ? (b1 - a1 + BK - 1) / BK : 0;
+    const int nst2 = b2 > a2 ? (b2 - a2 + BK - 1) / BK : 0;
+    const int nst = nst1 + nst2;
+    const int per = (nst + KG - 1) / KG;                    // slabs per group (the last groups may have fewer, or none)
+    const int s0 = grp * per;
+    const int mine = max(0, min(per, nst - s0));            // this group's slabs: s0 .. s0 + mine - 1
+
+    const int wm0 = (wq & 1) * 16, wn0 = (wq >> 1) * 16;
+    const int fi = lane & 15, fk = lane >> 4;
+    const unsigned lds0 = lds_offset_of(sm) + (unsigned)(grp * GRP);
+
+    auto pred = [&](const Operand<T>& o, int sidx, bool ok, int kk, int ke, bool need, bool& one) -> bool {
+        bool keep = ok && kk < ke;
+        one = false;
+        if (MASKED && need) {
+            const int sr = o.trans ? kk : sidx;
+            const int sc = o.trans ? sidx : kk;
+            const int d = sr - sc - o.moff;
+            const bool km = (o.mask == M_UPPER) ? (sr <= sc) : (o.mask == M_SUPPER) ? (sr < sc) : (o.mask == M_LOWER) ? (sr >= sc) : (d < 0);
+            one = keep && (o.mask == M_UNITTRAP) && (d == 0);
+            keep = keep && km;
+        }
+        return keep;
+    };
+    auto mask_active = [&](const Operand<T>& o, int x0, int bs, int kl) -> bool {
+        if (!MASKED || o.mask == M_NONE) return false;
+        const int dmin = o.trans ? kl - (x0 + bs - 1) : x0 - (kl + BK - 1);
+        const int dmax = o.trans ? kl + BK - 1 - x0 : x0 + bs - 1 - kl;
+        if (o.mask == M_UPPER) return dmax > 0;
+        if (o.mask == M_SUPPER) return dmax >= 0;
+        if (o.mask == M_LOWER) return dmin < 0;
+        return dmax - o.moff >= 0;
+    };
+    // wave wq of a group requests the fragment blocks (kb = wq, ib = 0, 1) of both operands: 4 instructions per slab and wave
+    auto request_operand = [&](const Operand<T>& o, const T* p, long ld, int x0, int xmax, int kl, int ke, unsigned dst) {
+        const long sidx = o.trans ? ld : 1, sk = o.trans ? 1 : ld;
+        const int kk = kl + wq * 4 + fk;
+        const bool need = mask_active(o, x0, 32, kl);
+        if (!need && x0 + 32 <= xmax && kl + BK <= ke) {
+            const T* src = p + (size_t)(x0 + fi) * sidx + (size_t)kk * sk;
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) lds_dma16(src + (size_t)(16 * ib) * sidx, dst + (unsigned)((wq * 2 + ib) * 1024));
+        } else {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                const int sx = x0 + 16 * ib + fi;
+                bool one;
+                const bool keep = pred(o, sx, sx < xmax, kk, ke, need, one);
+                const T* src = p + (size_t)sx * sidx + (size_t)kk * sk;
+                const T* alt = reinterpret_cast<const T*>(one ? g_dma_one : g_dma_zero);
+                lds_dma16(keep ? src : alt, dst + (unsigned)((wq * 2 + ib) * 1024));
+            }
+        }
+    };
+    auto request = [&](int s_, int st_) {                  // slab s_ (index in the tile's slab list) into this group's stage st_
+        const bool s2 = s_ >= nst1;
+        const int kl = s2 ? a2 + (s_ - nst1) * BK : a1 + s_ * BK;
+        const int ke = s2 ? b2 : b1;
+        const unsigned stage = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(st_ * STG)));
+        request_operand(opA, s2 ? opA.p2 : pa, s2 ? opA.ld2 : opA.ld, i0, M, kl, ke, stage);
+        request_operand(opB, s2 ? opB.p2 : pb, s2 ? opB.ld2 : opB.ld, j0, N, kl, ke, stage + OPB);
+    };
+
+    const bool use_c = g.kchunk == 0 && !(real_(g.beta) == 0.0 && imag_(g.beta) == 0.0);
+    const double sgnA = opA.conj ? -1.0 : 1.0, sgnB = opB.conj ? -1.0 : 1.0;
+    d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+    auto mma_slab = [&](int st_) {
+        const unsigned char* As = sm + grp * GRP + st_ * STG;
+        const unsigned char* Bs = As + OPB;
+#pragma unroll
+        for (int kb = 0; kb < BK / 4; ++kb) {
+            const d2 va = *reinterpret_cast<const d2*>(As + (kb * 2 + (wm0 >> 4)) * 1024 + lane * 16);
+            const double ar = va.x, ai = sgnA * va.y;
+#if EIG_WIDE_MFMA16
+            const d2 vb = *reinterpret_cast<const d2*>(Bs + (kb * 2 + (wn0 >> 4)) * 1024 + lane * 16);
+            const double br = vb.x, bi = sgnB * vb.y;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ar, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(bi, ar, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(bi, ai, acc0, 0, 0, 1);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(br, ai, acc1, 0, 0, 0);
+#else
+            // four v_mfma_f64_4x4x4 per block product (gemm_fast_kernel's round-1 form: the 4-row slices r of the B fragment,
+            // replicated over lane bits 2-3 -- here four broadcast reads of the fragment block --, against the unchanged A fragment;
+            // result r lands in component r): with four waves per SIMD the kernel is bound by the MFMA pipe, and the pipe runs this
+            // form at 72 TFLOP/s against 48 for 16x16x4 (profiles/r01_microbench3_mfma_variants.txt); same sums, same bits
+            double br[4], bi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const d2 vb = *reinterpret_cast<const d2*>(Bs + (kb * 2 + (wn0 >> 4)) * 1024 + ((4 * r + (lane & 3)) + 16 * fk) * 16);
+                br[r] = vb.x; bi[r] = sgnB * vb.y;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[r], ar, acc0[r], 0, 0, 0);
+                acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[r], ar, acc1[r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(bi[r], ai, acc0[r], 0, 0, 1);
+                acc1[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(br[r], ai, acc1[r], 0, 0, 0);
+            }
+#endif
+        }
+    };
+
+    // C of the tile (group 0 only): requested first, consumed last
+    T cv[4];
+    if (use_c && grp == 0) {
+        const int ldc_ = cold().ldc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = i0 + wm0 + fi, gj = j0 + wn0 + fk + 4 * r;
+            const bool ok = gi < M && gj < N;
+            const T* cp = ok ? pc + (size_t)gi + (size_t)gj * ldc_ : pc;
+            cv[r] = *cp;
+        }
+    }
+    // the group's first TWO slabs go out at once (both stages are free); from then on slab s + 2 follows the MFMAs of slab s
+    if (mine > 0) request(s0, 0);
+    if (mine > 1) request(s0 + 1, 1);
+    for (int s_ = 0; s_ < per; ++s_) {
+        // this wave's pieces of slab s_ have landed (the pieces of slab s_ + 1, requested later, may still fly: 4 instructions)
+        if (s_ + 1 < mine) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        __syncthreads();                                       // ... and so have the other waves' pieces
+        if (s_ < mine) mma_slab(s_ & 1);
+        if (s_ + 2 < per) {                                    // (a workgroup-uniform condition: the groups' slab counts differ)
+            __syncthreads();                                   // every wave of the workgroup is done reading stage s_ & 1
+            if (s_ + 2 < mine) request(s0 + s_ + 2, s_ & 1);
+        }
+    }
+    // partial tiles -> LDS (groups 1 .. KG - 1), summed by group 0 in the order of the groups
+    __syncthreads();
+    double* red = reinterpret_cast<double*>(sm);
+    if (grp > 0) {
+        double* dst = red + ((grp - 1) * 4 + wq) * 512 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dst[r * 64] = acc0[r]; dst[(4 + r) * 64] = acc1[r]; }
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int q = 1; q < KG; ++q) {
+        const double* src = red + ((q - 1) * 4 + wq) * 512 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc0[r] += src[r * 64]; acc1[r] += src[(4 + r) * 64]; }
+    }
+    ColdArgs& ge = cold();
+    const T al_ = cplx{ge.alpha.x, ge.alpha.y}, be_ = cplx{ge.beta.x, ge.beta.y};
+    T* const aux = ge.grp.count > 0 ? ge.grp.auxp[gq] : reinterpret_cast<T*>(ge.epi.aux);
+    T* const Pq = ge.grp.count > 0 ? ge.grp.Pp[gq] : ge.P;
+    const int pld = ge.M;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int gi = i0 + wm0 + fi, gj = j0 + wn0 + fk + 4 * r;
+        bool ok = gi < M && gj < N;
+        if (ge.epi.uplo == 1 && gi > gj) ok = false;
+        if (ge.epi.uplo == 2 && gi < gj) ok = false;
+        const T v = Tr<T>::make(acc0[r], acc1[r]);
+        if (ge.kchunk > 0) {
+            if (ok) Pq[(size_t)bz * ge.pstride + (size_t)gi + (size_t)gj * pld] = v;
+        } else {
+            T out = scal_(al_, v);
+            if (aux && ok) aux[(size_t)gi + (size_t)gj * ge.epi.ldaux] = out;
+            if (use_c) fma_(out, be_, cv[r]);
+            if (ge.epi.herm_diag && gi == gj) out = Tr<T>::realpart(out);
+            if (ok) pc[(size_t)gi + (size_t)gj * ge.ldc] = out;
+        }
     }
 }
 
@@ -916,7 +1185,7 @@ template <class T> static dim3 choose_map(GemmArgs<T>& g, int tm, int tn, bool t
 }
 
 template <class T, int BM, int BN>
-static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map, int dma = 0) {
+static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, bool use_map, int dma = 0, bool lean = false) {
     constexpr int BK = slab_k<T>(BM * BN <= 32 * 32);
     GemmArgs<T> g = g_in;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -932,8 +1201,11 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, boo
             const long total = (long)grid.x * grid.y * grid.z;
             const int pers = total > dma;
             const dim3 pg = pers ? dim3((unsigned)dma) : grid;
-            if (masked) hipLaunchKernelGGL((gemm_dma_kernel<true>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
-            else hipLaunchKernelGGL((gemm_dma_kernel<false>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
+            if (lean) {
+                if (masked) hipLaunchKernelGGL((gemm_dma_kernel<true, 8, 3>), grid, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, 0);
+                else hipLaunchKernelGGL((gemm_dma_kernel<false, 8, 3>), grid, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, 0);
+            } else if (masked) hipLaunchKernelGGL((gemm_dma_kernel<true, BKL, 2>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
+            else hipLaunchKernelGGL((gemm_dma_kernel<false, BKL, 2>), pg, block, 0, st, g, (int)grid.x, (int)grid.y, (int)grid.z, pers);
             EIG_HIP(hipGetLastError());
             return;
         }
@@ -950,6 +1222,23 @@ static void launch_gemm(hipStream_t st, const GemmArgs<T>& g_in, int splits, boo
 #undef EIG_LAUNCH_FAST
     EIG_HIP(hipGetLastError());
 }
+
+static void launch_gemm_wide(hipStream_t st, const GemmArgs<cplx>& g_in, int zdim, bool use_map, int kg) {
+    GemmArgs<cplx> g = g_in;
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    const bool tri = g.epi.uplo != 0 && tm == tn;
+    const dim3 grid = choose_map(g, tm, tn, tri, zdim, use_map);
+    const bool masked = g.A.mask != M_NONE || g.B.mask != M_NONE;
+    if (kg == 4) {
+        if (masked) hipLaunchKernelGGL((gemm_wide_kernel<true, 4>), grid, dim3(1024), 0, st, g);
+        else hipLaunchKernelGGL((gemm_wide_kernel<false, 4>), grid, dim3(1024), 0, st, g);
+    } else {
+        if (masked) hipLaunchKernelGGL((gemm_wide_kernel<true, 2>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_wide_kernel<false, 2>), grid, dim3(512), 0, st, g);
+    }
+    EIG_HIP(hipGetLastError());
+}
+static void launch_gemm_wide(hipStream_t, const GemmArgs<double>&, int, bool, int) {}
 
 template <class T> static void dispatch_gemm_now(Ctx& c, hipStream_t st, const GemmArgs<T>& g, int splits, int ngroup);
 
@@ -1042,9 +1331,30 @@ template <class T> static void dispatch_gemm_now(Ctx& c, hipStream_t st, const G
         const int kitem = g.kchunk > 0 ? g.kchunk : g.K + (g.bt.count > 0 && g.bt.dK > 0 ? (g.bt.count - 1) * g.bt.dK : 0);
         int dma = c.gemm_dma == 0 ? 0 : ((c.gemm_dma == 2 && ngroup == 1) ? 2 * c.n_cu : INT_MAX);
         if (c.gemm_dma == 3 && kitem < kGemmDmaMinK) dma = 0;
-        launch_gemm<T, 64, 64>(st, g, splits * ngroup, c.tile_map != 0, dma);
+        // short-K items: the lean LDS-DMA form (three workgroups per CU), option "gemm_lean" = the largest K it serves
+        // (only where the launch is several rounds of tiles: with <= 2 rounds the lean form's later C fetch is exposed -- her2k n = 1024
+        //  16.0 -> 18.6 us, n = 2048 unchanged, n >= 3000 -5..7 %)
+        const long tm64 = (g.M + 63) / 64, tn64 = (g.N + 63) / 64;
+        const long active = (g.epi.uplo != 0 && tm64 == tn64 ? tm64 * (tm64 + 1) / 2 : tm64 * tn64) * splits * ngroup;
+        const bool lean = Tr<T>::cx && c.gemm_lean > 0 && kitem <= c.gemm_lean && active >= 4L * c.n_cu;
+        if (lean) dma = INT_MAX;
+        launch_gemm<T, 64, 64>(st, g, splits * ngroup, c.tile_map != 0, dma, lean);
     }
-    else launch_gemm<T, 32, 32>(st, g, splits * ngroup, c.tile_map != 0);
+    else {
+        if constexpr (Tr<T>::cx) {
+            // whole-CU workgroups (gemm_wide_kernel): chosen from the problem's OWN tile count (not the group's) -- see the kernel
+            const long items = (long)((g.M + 31) / 32) * ((g.N + 31) / 32) * splits;
+            const int kitem = g.kchunk > 0 ? g.kchunk : g.K;
+            int kg = 0;
+            if (c.gemm_wide >= 1 && items <= c.n_cu) kg = 4;
+            else if (c.gemm_wide >= 2 && items <= 2L * c.n_cu) kg = 2;
+            if (kg > 0 && kitem >= BKL * kg) {
+                launch_gemm_wide(st, g, splits * ngroup, c.tile_map != 0, kg);
+                return;
+            }
+        }
+        launch_gemm<T, 32, 32>(st, g, splits * ngroup, c.tile_map != 0);
+    }
 }
 
 template <class T>

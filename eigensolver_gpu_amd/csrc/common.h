@@ -137,6 +137,14 @@ inline int norm_trsm_base(int v) { return v >= 1024 ? 1024 : (v >= 512 ? 512 : (
 // at K = 64, profiles/r06_experiments.txt section 2); results are bit-identical in every form
 constexpr int kGemmDmaDefault = 3;
 constexpr int kGemmDmaMinK = 96;
+// MFMA engine, complex products with fewer than one 64 x 64 tile per CU: 0 = 32 x 32 tiles on four-wave workgroups (gemm_fast_kernel), 1 =
+// 32 x 32 tiles on whole-CU workgroups of 16 waves with K split inside the workgroup where the launch has at most one tile per CU
+// (gemm_wide_kernel<.., 4>), 2 = that, and 8-wave workgroups (two per CU) up to two tiles per CU (see kGemmWideDefault in blas3.hip's
+// dispatch_gemm_now; the choice is a function of the product's shape only)
+constexpr int kGemmWideDefault = 0;
+// MFMA engine, complex 64 x 64 tiles: work items with at most this much of K run on the lean LDS-DMA form (K-slabs of 8, C fetched in the
+// epilogue, three workgroups per CU: gemm_dma_kernel<., 8, 3>); 0 = never.  Bit-identical to the other forms.
+constexpr int kGemmLeanDefault = 0;
 constexpr int kMvDmaDefault = 0;   // (set from the measurements of round 6, profiles/r06_experiments.txt)
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;
@@ -174,6 +182,8 @@ struct Ctx {
     int bt_nb = kBtNbDefault;
     int hemv_blocks = 0;  // 0 = auto
     int gemm_dma = kGemmDmaDefault;   // staging path of the complex 64 x 64 tiles (see kGemmDmaDefault)
+    int gemm_lean = kGemmLeanDefault; // largest K of a work item served by the lean LDS-DMA form (see kGemmLeanDefault)
+    int gemm_wide = kGemmWideDefault; // whole-CU workgroups for the complex 32 x 32 tiles (see kGemmWideDefault)
     int mv_dma = kMvDmaDefault;   // smallest trailing order for which the panel mat-vec streams its tiles through the LDS-DMA ring
                              // (panel_mv_kernel<T, NB, true> in trd.hip); 0 = never (the register-staged form everywhere)
     int use_graph = 0;       // replay the tridiagonalization launch sequence as a hipGraph (EIGSOLVE_GRAPH=1 / option "graph");

@@ -243,7 +243,7 @@ void copy_options(Ctx& c, const Ctx& d) {
     c.trsm_base = d.trsm_base; c.potrf_mode = d.potrf_mode; c.gst_mode = d.gst_mode; c.gst_thr = d.gst_thr;
     c.tridiag_device = d.tridiag_device; c.real_il_reference = d.real_il_reference; c.tile_map = d.tile_map;
     c.batch_workers = d.batch_workers; c.trace_marks = d.trace_marks; c.batch_fuse = d.batch_fuse; c.batch_zip = d.batch_zip; c.trd_finish = d.trd_finish;
-    c.zs_cap_mb = d.zs_cap_mb; c.mv_dma = d.mv_dma; c.gemm_dma = d.gemm_dma;
+    c.zs_cap_mb = d.zs_cap_mb; c.mv_dma = d.mv_dma; c.gemm_dma = d.gemm_dma; c.gemm_wide = d.gemm_wide; c.gemm_lean = d.gemm_lean;
 }
 
 // ---- the library's worker threads ------------------------------------------------------------------------------------
@@ -387,7 +387,7 @@ void stream_pool_finalize(int dev) {
 // same value semantics, plus the words "host" / "device" for TRIDIAG and "rec" for POTRF) go through apply_option.
 static const char* const kOptionNames[] = {"trd_nb", "bt_nb", "hemv_blocks", "real_il_reference", "graph", "overlap", "trsm_base",
                                            "potrf", "gst", "gst_thr", "batch_workers", "batch_fuse", "batch_zip", "tridiag", "tile_map",
-                                           "trd_finish", "trace_marks", "zs_cap_mb", "mv_dma", "gemm_dma"};
+                                           "trd_finish", "trace_marks", "zs_cap_mb", "mv_dma", "gemm_dma", "gemm_wide", "gemm_lean"};
 bool apply_option(Ctx& c, const std::string& s, int value) {
     if (s == "trd_nb") { c.trd_nb = (value <= 0 || value > 64) ? kTrdNbDefault : value; c.drop_graphs(); }
     else if (s == "bt_nb") c.bt_nb = norm_bt_nb(value);
@@ -408,6 +408,8 @@ bool apply_option(Ctx& c, const std::string& s, int value) {
     else if (s == "trace_marks") c.trace_marks = value > 0;
     else if (s == "zs_cap_mb") c.zs_cap_mb = value <= 0 ? kZsCapMbDefault : value;
     else if (s == "gemm_dma") c.gemm_dma = (value < 0 || value > 3) ? kGemmDmaDefault : value;
+    else if (s == "gemm_lean") c.gemm_lean = value < 0 ? kGemmLeanDefault : value;
+    else if (s == "gemm_wide") c.gemm_wide = (value < 0 || value > 2) ? kGemmWideDefault : value;
     else if (s == "mv_dma") { c.mv_dma = value < 0 ? kMvDmaDefault : value; c.drop_graphs(); }
     else return false;
     return true;

@@ -462,9 +462,11 @@ __global__ void __launch_bounds__(DMA ? MVD : MVT, DMA ? 2 : 3) panel_mv_kernel(
     // kernel boundaries, profiles/r04_experiments.txt 15; walked in one direction an LRU cache smaller than the stream never hits).
     // Every tile writes its own slots of the partial array, so only the order of the per-workgroup sum S changes with the direction.
     const int KT = (hb < ntiles && !is_gemv) ? (ntiles - hb + a.gh - 1) / a.gh : 0;
-    // (only where the launch's stream exceeds what the L2s keep anyway: below ~24 MB every order hits, and the ascending one measured
-    //  2 % faster there -- dsytrd N=2048 sweep 9.26 vs 9.46 ms)
-    const bool rev = EIG_MV_SNAKE && !plain && (i & 1) && (size_t)ntiles * NB * (HT * HT * sizeof(T)) > ((size_t)24 << 20);
+    // (only where ONE problem's stream exceeds what the L2s keep anyway: below ~24 MB every order hits, and the ascending one measured
+    //  2 % faster there -- dsytrd N=2048 sweep 9.26 vs 9.46 ms.  The rule must not look at NB: the direction decides the order of
+    //  the sum S, and a problem solved inside a lockstep group has to give the bits it gives alone -- with the group's stream in
+    //  the rule the problems of a C5 batch differed from their single solves in the last bits: test_c5_full_size_batch_all_64_problems)
+    const bool rev = EIG_MV_SNAKE && !plain && (i & 1) && (size_t)ntiles * (HT * HT * sizeof(T)) > ((size_t)24 << 20);
     auto tile_at = [&](int k) -> int { return hb + (rev ? KT - 1 - k : k) * a.gh; };
     int I = 0, J = 0, t = KT > 0 ? tile_at(0) : ntiles;
     if constexpr (DMA) {

@@ -181,6 +181,66 @@ def test_gemm_staging_paths_vs_numpy(env, ta, tb, dims, mode):
     assert np.array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("ta,tb,dims", [("N", "N", (256, 1024, 256)), ("C", "N", (512, 1024, 512)), ("N", "C", (250, 1000, 130)),
+                                        ("T", "T", (100, 90, 64)), ("C", "C", (512, 500, 70)), ("C", "N", (96, 96, 4100)),
+                                        ("N", "N", (33, 31, 1000)), ("N", "C", (700, 300, 48))])
+def test_gemm_whole_cu_workgroups_vs_numpy(env, ta, tb, dims, mode):
+    """Complex products of fewer than one 64 x 64 tile per CU run on 32 x 32 tiles: on four-wave workgroups (option "gemm_wide" = 0)
+    or on whole-CU workgroups with K split inside the workgroup (gemm_wide_kernel: 16 waves up to one tile per CU, 8 waves up to
+    two) -- every form against numpy, ragged edges and K remainders included; the forms sum over k in different orders and agree
+    with each other to rounding."""
+    torch, oracle, api = env
+    M, N, K = dims
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    A = rnd(rng, True, M, K) if ta == "N" else rnd(rng, True, K, M)
+    B = rnd(rng, True, K, N) if tb == "N" else rnd(rng, True, N, K)
+    C = rnd(rng, True, M, N)
+    f = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    al, be = (0.7 - 0.2j), (0.3 + 0.1j)
+    ref = al * (f[ta](A) @ f[tb](B)) + be * C
+    try:
+        api.set_option("gemm_wide", mode)
+        Cd = api.to_device(C)
+        api.gemm(ta, tb, M, N, K, al, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], be, Cd, M)
+        got = api.to_host(Cd)
+        Cn = api.to_device(np.full_like(C, np.nan))       # beta = 0 must not read C
+        api.gemm(ta, tb, M, N, K, 1.0, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], 0.0, Cn, M)
+        got0 = api.to_host(Cn)
+        Cd2 = api.to_device(C)
+        api.gemm(ta, tb, M, N, K, al, api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], be, Cd2, M)
+    finally:
+        api.set_option("gemm_wide", -1)
+    assert rel(got, ref) <= 20 * K * EPS
+    assert rel(got0, f[ta](A) @ f[tb](B)) <= 20 * K * EPS
+    assert np.array_equal(got, api.to_host(Cd2))          # fixed summation order: run to run bit-identical
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,k", [(500, 32), (700, 17), (333, 64), (130, 7)])
+def test_her2k_whole_cu_workgroups(env, n, k, mode):
+    """K-concatenated operands (two segments, any boundary) and triangular output on the whole-CU workgroups."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(n + k)
+    V, W = rnd(rng, True, n, k), rnd(rng, True, n, k)
+    C = rnd(rng, True, n, n)
+    C = C + C.conj().T
+    Cin = np.triu(C).copy()
+    Cin[np.tril_indices(n, -1)] = 7.5
+    try:
+        api.set_option("gemm_wide", mode)
+        Cd = api.to_device(Cin)
+        api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+        got = api.to_host(Cd)
+    finally:
+        api.set_option("gemm_wide", -1)
+    ref = C - V @ W.conj().T - W @ V.conj().T
+    iu = np.triu_indices(n)
+    assert np.abs(got[iu] - ref[iu]).max() <= 50 * k * EPS * np.abs(ref).max()
+    assert np.all(got[np.tril_indices(n, -1)] == 7.5)
+    assert np.all(got.diagonal().imag == 0)
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("n,k", [(2600, 64), (2111, 50), (1999, 17)])
 def test_her2k_staging_paths(env, n, k, mode):
@@ -203,6 +263,47 @@ def test_her2k_staging_paths(env, n, k, mode):
     iu = np.triu_indices(n)
     assert np.abs(outs[1][iu] - ref[iu]).max() <= 50 * k * EPS * np.abs(ref).max()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("what", [("gemm", "N", "N", (1024, 1024, 64)), ("gemm", "C", "N", (1030, 1000, 77)), ("gemm", "N", "C", (2048, 1024, 300)),
+                                  ("gemm", "T", "T", (999, 1100, 8)), ("her2k", 2600, 32), ("her2k", 2111, 50), ("her2k", 3000, 64)])
+def test_lean_dma_form_is_bit_identical(env, what):
+    """Option "gemm_lean": short-K work items of the complex 64 x 64 tiles on K-slabs of 8 with C fetched in the epilogue (three to
+    four workgroups per CU) -- bit for bit the register-staged kernel's results, plain products and K-concatenated triangular
+    updates, ragged edges and K remainders included."""
+    torch, oracle, api = env
+    rng = np.random.default_rng(11)
+    f = {"N": lambda x: x, "T": lambda x: x.T, "C": lambda x: x.conj().T}
+    outs = []
+    try:
+        for lean, dma in ((0, 0), (1 << 20, -1), (0, -1)):
+            api.set_option("gemm_dma", dma)
+            api.set_option("gemm_lean", lean)
+            rng = np.random.default_rng(11)
+            if what[0] == "gemm":
+                _, ta, tb, (M, N, K) = what
+                A = rnd(rng, True, M, K) if ta == "N" else rnd(rng, True, K, M)
+                B = rnd(rng, True, K, N) if tb == "N" else rnd(rng, True, N, K)
+                C = rnd(rng, True, M, N)
+                Cd = api.to_device(C)
+                api.gemm(ta, tb, M, N, K, (0.7 - 0.2j), api.to_device(A), A.shape[0], api.to_device(B), B.shape[0], (0.3 + 0.1j), Cd, M)
+                ref = (0.7 - 0.2j) * (f[ta](A) @ f[tb](B)) + (0.3 + 0.1j) * C
+                tol = 20 * K * EPS
+            else:
+                _, n, k = what
+                V, W = rnd(rng, True, n, k), rnd(rng, True, n, k)
+                C = rnd(rng, True, n, n)
+                C = C + C.conj().T
+                Cd = api.to_device(C)
+                api.her2k(api.to_device(V), api.to_device(W), Cd, n, k)
+                ref = np.triu(C - V @ W.conj().T - W @ V.conj().T) + np.tril(C, -1)
+                tol = 50 * k * EPS
+            outs.append(api.to_host(Cd))
+    finally:
+        api.set_option("gemm_dma", -1)
+        api.set_option("gemm_lean", -1)
+    assert rel(outs[1], ref) <= tol
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("cplx", [False, True])

@@ -109,4 +109,29 @@ if "rate" in what:
                 ms = api.her2k_bench(V, W, Cn, n, k, reps=10)
                 row.append("%s %7.1f us %5.1f TF" % (("reg", "dma", "dmaP")[mode], ms * 1e3, 8.0 * n * n * k / (ms * 1e-3) * 1e-12))
         print("her2k n=%d k=%d: %s" % (n, k, " | ".join(row)), flush=True)
+
+if "lean" in what:
+    # option "gemm_lean": K-slabs of 8, C fetched in the epilogue, three to four workgroups per CU (gemm_dma_kernel<., 8, 3>) against the
+    # default choice (registers below 96 of K, LDS-DMA with slabs of 16 above)
+    big = 4096
+    A = rnd(big, big); B = rnd(big, big); C = torch.empty((big, big), dtype=dt, device="cuda")
+    api.set_option("gemm_dma", -1)
+    print("default | lean", flush=True)
+    for ta, tb, M, N, K in [("N", "C", 4096, 4096, 64), ("N", "C", 4096, 4096, 128), ("C", "N", 4032, 4032, 128), ("N", "C", 4096, 1024, 256),
+                            ("N", "C", 2048, 2048, 64), ("N", "C", 2048, 2048, 128), ("N", "N", 2048, 2048, 512), ("N", "N", 4096, 4096, 1024)]:
+        row = []
+        for lean in (0, 1 << 20, 0, 1 << 20):
+            api.set_option("gemm_lean", lean)
+            ms = api.gemm_bench(ta, tb, M, N, K, A, big, B, big, C, big, reps=10)
+            row.append("%8.1f us %5.1f TF" % (ms * 1e3, 8.0 * M * N * K / (ms * 1e-3) * 1e-12))
+        print("%s%s %5d %5d %5d: %s" % (ta, tb, M, N, K, " | ".join(row)), flush=True)
+    for n, k in ((4096, 64), (4096, 32), (3000, 32), (2048, 32), (1024, 32)):
+        V = rnd(k, n); W = rnd(k, n); Cn = rnd(n, n)
+        row = []
+        for lean in (0, 1 << 20, 0, 1 << 20):
+            api.set_option("gemm_lean", lean)
+            ms = api.her2k_bench(V, W, Cn, n, k, reps=10)
+            row.append("%7.1f us %5.1f TF" % (ms * 1e3, 8.0 * n * n * k / (ms * 1e-3) * 1e-12))
+        print("her2k n=%d k=%d: %s" % (n, k, " | ".join(row)), flush=True)
+    api.set_option("gemm_lean", -1)
 api.set_option("gemm_dma", -1)
