@@ -139,12 +139,17 @@ constexpr int kGemmDmaDefault = 3;
 constexpr int kGemmDmaMinK = 96;
 // MFMA engine, complex products with fewer than one 64 x 64 tile per CU: 0 = 32 x 32 tiles on four-wave workgroups (gemm_fast_kernel), 1 =
 // 32 x 32 tiles on whole-CU workgroups of 16 waves with K split inside the workgroup where the launch has at most one tile per CU
-// (gemm_wide_kernel<.., 4>), 2 = that, and 8-wave workgroups (two per CU) up to two tiles per CU (see kGemmWideDefault in blas3.hip's
-// dispatch_gemm_now; the choice is a function of the product's shape only)
+// (gemm_wide_kernel<.., 4>), 2 = that, and 8-wave workgroups (two per CU) up to two tiles per CU (dispatch_gemm_now in blas3.hip; the
+// choice is a function of the product's shape only).  Off: 0-10 % faster on the bare shapes (256 x 1024 x 256: 18.9 -> 17.1 us), within
+// noise in the C3 solve (gst + back-transformation + trsm 12.8 -> 12.6 ms), 1-2 % SLOWER in batches (C3 18.0 -> 17.8, C5 108.8 -> 106.4
+// problems/s: a 1024-thread workgroup with 128 KB of LDS needs an empty CU, which the other launch chains rarely leave), and the K-split
+// changes the summation order (profiles/r06_experiments.txt section 8)
 constexpr int kGemmWideDefault = 0;
 // MFMA engine, complex 64 x 64 tiles: work items with at most this much of K run on the lean LDS-DMA form (K-slabs of 8, C fetched in the
-// epilogue, three workgroups per CU: gemm_dma_kernel<., 8, 3>); 0 = never.  Bit-identical to the other forms.
-constexpr int kGemmLeanDefault = 0;
+// epilogue, 116 VGPRs and 32 KB of LDS: four workgroups per CU, gemm_dma_kernel<., 8, 3>) when the launch has at least four tiles per CU;
+// 0 = never.  Bit-identical to the other forms.  Measured (profiles/r06_experiments.txt section 9): her2k n = 4096 k = 32 / 64 +5 / +6 %,
+// n = 3000 +7 %, the factorization's rank-128 update of order 4032 +7 %; in the C3 solve -0.3 ms, C4 -2.5 ms, batch rates unchanged.
+constexpr int kGemmLeanDefault = 128;
 constexpr int kMvDmaDefault = 0;   // (set from the measurements of round 6, profiles/r06_experiments.txt)
 // Upper bound of the "hemv_blocks" knob (workgroups of the panel mat-vec kernel; sizes the per-workgroup partial array)
 constexpr int kHemvBlocksMax = 8192;

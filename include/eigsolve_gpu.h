@@ -96,12 +96,18 @@ int eigsolve_set_host_threads(int nthreads);
  *               1 = LDS-DMA (global_load_lds_dwordx4 into fragment-ordered LDS blocks, gemm_dma_kernel), 2 = LDS-DMA with persistent
  *               workgroups, 3 (default) = LDS-DMA for work items with at least 96 of K, registers below.  Same summation order and
  *               lane mapping in every form: results are bit-identical.
+ *   "gemm_lean" largest K of a work item of the complex 64 x 64 tiles that runs on the lean LDS-DMA form (K-slabs of 8, the C tile fetched
+ *               in the epilogue: 116 VGPRs, 32 KB of LDS, four workgroups per CU instead of two) when the launch has at least four
+ *               tiles per CU -- the trailing rank-2nb updates of the tridiagonalization and the rank-128 updates of the
+ *               factorization at orders >= ~3000.  Default 128, 0 = never.  Bit-identical to the other forms.
  *   "gemm_wide" complex products with fewer than one 64 x 64 tile per CU (base cases of the triangular solves, W T^H of the
  *               back-transformation, merges of inverse blocks): 0 = 32 x 32 tiles on four-wave workgroups, 1 = 32 x 32 tiles on
  *               whole-CU workgroups (16 waves, K split inside the workgroup, partial tiles summed through LDS in a fixed order:
- *               gemm_wide_kernel) for launches of at most one tile per CU, 2 (default) = also 8-wave workgroups up to two tiles per
- *               CU.  The summation order over k differs between the forms (results agree to rounding); the form is chosen from the
- *               product's shape alone, so every execution mode of a solve stays bit-identical to every other.
+ *               gemm_wide_kernel) for launches of at most one tile per CU, 2 = also 8-wave workgroups up to two tiles per
+ *               CU.  Default 0: +0-10 % on the bare shapes, nothing in a solve, -1..2 % in batches (profiles/r06_experiments.txt
+ *               section 8).  The summation order over k differs between the forms (results agree to rounding); the form is chosen from the
+ *               product's shape alone; execution modes that cut a product's output differently (the potrf || hegst pipeline) then differ in the
+ *               last bits, which they never do with the option off.
  *   "mv_dma"    smallest trailing order from which the panel mat-vec streams its tiles through an LDS-DMA ring instead of registers
  *               (0 = never, the default: measured slower at every order, profiles/r06_experiments.txt section 1); bit-identical results.
  * Returns 0 / -1 (unknown name). */

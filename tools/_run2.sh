@@ -1,8 +1,9 @@
-cd $GRAFT_REPO_ROOT
-export GPU_MAX_HW_QUEUES=8
-L=$PWD/eigensolver_gpu_amd/lib
-timeout 600 python tools/mv_dma_ab.py check 2>&1 | grep -v "True  rel\|True  finite" | tail -5
-for m in 0 1; do EIGSOLVE_MV_DMA=$m EIGSOLVE_GPU_LIB=$L/v_timing/libeigsolve_gpu.so timeout 600 python tools/trd_phase_timing.py 2>&1 | grep -v "amdgpu.ids\|row"; done > gpurun_out/r06_mv_stamps3.txt
-cat gpurun_out/r06_mv_stamps3.txt
-timeout 600 python tools/mv_dma_ab.py rate 2>&1 | grep "hemv" > gpurun_out/r06_mv_rate2.txt; cat gpurun_out/r06_mv_rate2.txt
-timeout 900 python tools/mv_dma_ab.py trd 2>&1 | grep "N=" > gpurun_out/r06_mv_trd2.txt; cat gpurun_out/r06_mv_trd2.txt
+#!/bin/bash
+# round 6, session 5: lean LDS-DMA form with the tile-count rule -- repeated A/B (shapes, isolated phases, batch rates)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=gpurun_out/w3; mkdir -p $O
+(timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "whole_cu or lean_dma or optional_execution or staging_paths" 2>&1 | tail -4) > $O/pytest.log
+tail -2 $O/pytest.log
+for i in 1 2 3; do python tools/gemm_dma_ab.py lean 2>&1 | grep -v amdgpu.ids; done | tee $O/lean_ab.txt
+bash tools/ab_sweep.sh w3 iso 4096 1024 cplx 7 -- "EIGSOLVE_OVERLAP=0" "EIGSOLVE_OVERLAP=0 EIGSOLVE_GEMM_LEAN=64" "EIGSOLVE_OVERLAP=0 EIGSOLVE_GEMM_LEAN=128" "EIGSOLVE_OVERLAP=0" "EIGSOLVE_OVERLAP=0 EIGSOLVE_GEMM_LEAN=64" "EIGSOLVE_OVERLAP=0 EIGSOLVE_GEMM_LEAN=128"
+bash tools/ab_sweep.sh w3c3 c3 -- "" "EIGSOLVE_GEMM_LEAN=128" "" "EIGSOLVE_GEMM_LEAN=128" "EIGSOLVE_GEMM_LEAN=64" ""
+bash tools/ab_sweep.sh w3c4 c4 -- "" "EIGSOLVE_GEMM_LEAN=128" "" "EIGSOLVE_GEMM_LEAN=128"
