@@ -542,7 +542,7 @@ def main():
         per_launch_bytes = r["algo_bytes"] / r["launches"]
         ach = r["algo_bytes"] / (r["ms_total"] * 1e-3) * 1e-9
         tfp = None
-        for nm in ("r05_hemv_traffic.json", "r04_hemv_traffic.json", "r03_hemv_traffic.json", "r02_hemv_traffic.json", "hemv_traffic.json"):
+        for nm in ("r06_hemv_traffic.json", "r05_hemv_traffic.json", "r04_hemv_traffic.json", "r03_hemv_traffic.json", "r02_hemv_traffic.json", "hemv_traffic.json"):
             tp = os.path.join(ROOT, "profiles", nm)
             if os.path.exists(tp):
                 try:

@@ -44,10 +44,11 @@ def short(nm):
 N = 4096
 KNOWN = {
     # (round 4: the mat-vec grid is one workgroup per CU, the products launch 1-D grids of 64-tile super-tiles -- blas3.hip tile_of)
-    ("panel_mv_kernel<z,1>", str(256 * 320)): (16 * N * (N + 1) // 2, "hemv n=4096: s n(n+1)/2"),
-    ("panel_mv_kernel<d,1>", str(256 * 320)): (8 * 2048 * 2049 // 2, "symv n=2048: s n(n+1)/2"),
-    ("gemmF<z,64,64,0,1,16,false>", str(64 * 64 * 256)): (3 * 16 * N * N, "zgemm 4096^3: A + B + C once"),
-    ("gemmF<z,64,64,0,0,16,false>", str(2176 * 256)): (2 * 16 * N * 64 + 2 * 16 * N * (N + 1) // 2, "zher2k k=64: V, W + upper(C) read and written"),
+    # (round 6: the mat-vec kernel has a data-path template argument; the complex 64 x 64 tiles run on gemm_dma_kernel)
+    ("panel_mv_kernel<z,1,", str(256 * 320)): (16 * N * (N + 1) // 2, "hemv n=4096: s n(n+1)/2"),
+    ("panel_mv_kernel<d,1,", str(256 * 320)): (8 * 2048 * 2049 // 2, "symv n=2048: s n(n+1)/2"),
+    ("gemm_dma_kernel<false,16,2>", str(64 * 64 * 256)): (3 * 16 * N * N, "zgemm 4096^3: A + B + C once"),
+    ("gemm_dma_kernel<false,8,3>", str(2176 * 256)): (2 * 16 * N * 64 + 2 * 16 * N * (N + 1) // 2, "zher2k k=64: V, W + upper(C) read and written"),
 }
 
 rows = []
