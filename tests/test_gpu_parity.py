@@ -1202,7 +1202,7 @@ def _report(name, obj):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = os.path.join(root, "gpurun_out")
     os.makedirs(d, exist_ok=True)
-    path = os.path.join(d, "r05_parity_full_size.json")
+    path = os.path.join(d, "r06_parity_full_size.json")
     cur = {}
     if os.path.exists(path):
         try:
