@@ -72,10 +72,11 @@ int eigsolve_set_host_threads(int nthreads);
  *               allows >= 5 hardware queues through GPU_MAX_HW_QUEUES, else 3; 0 = lockstep form on the caller's context).
  *   "batch_fuse" problems per launch chain of a batch call that share the per-column launches of the tridiagonalization
  *               (lockstep groups, 1..4; default automatic: min(4, problems / chains) while a matrix is <= 96 MiB, else 1).
- *   "batch_zip" 1 (default) = inside a lockstep group the BLAS-3 phases (inverse blocks, reduction to standard form, back-
- *               transformation, final solve) run as ONE launch sequence for the group: every product on the MFMA engine carries all
- *               problems of the group (pointer table, blockIdx.z = problem x K-split), every other kernel is launched once per
- *               problem at its position; 0 = problem after problem.  Same kernels, tiles and K order per problem: bit-identical.
+ *   "batch_zip" inside a lockstep group the BLAS-3 phases run as ONE launch sequence for the group: every product on the MFMA engine
+ *               carries all problems of the group (pointer table, blockIdx.z = problem x K-split), every other kernel is launched
+ *               once per problem at its position.  Bit 0 = the phases in front of the tridiagonalization (inverse blocks, reduction
+ *               to standard form), bit 1 = those behind it (back-transformation, final solve); default 3, 0 = problem after
+ *               problem.  Same kernels, tiles and K order per problem: bit-identical.
  *   "real_il_reference" 1 = dsygvdx/dsyevd return eigenvectors 1..m whatever il is, as the real reference path does
  *               (dsyevd_gpu.F90:108); 0 (default) = il is honoured like in the complex path (zheevd_gpu.F90:110).
  *   "graph"     1 = the tridiagonalization's ~2N dependent launches are captured once per (type, N) on an internal working
