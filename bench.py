@@ -590,7 +590,7 @@ def main():
         rh = api.hetrd_her2k_sweep(C, Wp, 0, reps=2)
         Bm = torch.randn((n, n), dtype=dt, device=dev)
         Cm = torch.empty((n, n), dtype=dt, device=dev)
-        msg = api.gemm_bench("N", "N", n, n, n, A0, n, Bm, n, Cm, n, reps=3)
+        msg = api.gemm_bench("N", "N", n, n, n, A0, n, Bm, n, Cm, n, reps=8)
         fl_gemm = cmul * 2.0 * n ** 3
         blas3_ms = ph["potrf"] + ph["gst"] + ph["backtransform"] + ph["trsm"]
         ph1 = one_stream["phase_ms"] if one_stream else ph
