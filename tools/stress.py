@@ -33,7 +33,11 @@ for case in range(cases):
             "gst_thr": int(rng.choice([256, 512, 1024])), "trsm_base": int(rng.choice([64, 256, 256, 512, 1024])),
             "trd_nb": int(rng.choice([64, 32, 17])), "potrf": int(rng.choice([2, 2, 1, 0])), "zs_cap_mb": int(rng.choice([0, 0, 0, 1])), "trd_finish": int(rng.choice([-1, -1, 32, 64, 100])),
             "tile_map": int(rng.integers(0, 2)), "hemv_blocks": int(rng.choice([0, 0, 0, 3, 40, 512])),
-            "batch_workers": int(rng.choice([-1, -1, 0, 2])), "batch_fuse": int(rng.choice([-1, -1, 1, 3]))}
+            "batch_workers": int(rng.choice([-1, -1, 0, 2])), "batch_fuse": int(rng.choice([-1, -1, 1, 3])),
+            # round 6: staging paths of the MFMA engine, the lean / whole-CU forms, the mat-vec's LDS-DMA ring, zipped group launches,
+            # the look-ahead factorization
+            "gemm_dma": int(rng.choice([3, 3, 0, 1, 2])), "gemm_lean": int(rng.choice([128, 128, 0, 1 << 20])), "gemm_wide": int(rng.choice([0, 0, 1, 2])),
+            "mv_dma": int(rng.choice([0, 0, 1, 600])), "batch_zip": int(rng.choice([3, 3, 0, 1, 2])), "overlap": int(rng.choice([3, 3, 0, 7, 4]))}
     # one case in five goes through the batch entry point: 2-5 distinct problems of this order in one call, each checked
     # (the batch interface carries no host workspaces: it needs the device tridiagonal solver and says so otherwise)
     nprob = int(rng.integers(2, 6)) if (rng.random() < 0.2 and n <= 700) else 1
@@ -61,5 +65,7 @@ for k in ("tridiag", "gst"): api.set_option(k, -1)
 for k in ("bt_nb", "gst_thr", "trsm_base", "trd_nb"): api.set_option(k, 0)
 api.set_option("potrf", -1); api.set_option("trd_finish", -1); api.set_option("tile_map", 1); api.set_option("zs_cap_mb", 0)
 api.set_option("hemv_blocks", 0); api.set_option("batch_workers", -1); api.set_option("batch_fuse", -1)
+for k in ("gemm_dma", "gemm_lean", "gemm_wide", "mv_dma", "overlap"): api.set_option(k, -1)
+api.set_option("batch_zip", 3)
 print("%d cases, %d bad, %.1f s" % (cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
